@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- MPC solves/sec of the batched BiConvex MPC solve on MI355X.
+
+One "step" = one pass of the hot path over one batch: B independent
+BiconvexMP.optimize(x_init, 10) solves (Solo12 trot, H = 20, fp64, perturbed initial
+conditions; SURVEY.md 8d config 2 at the batch size of north_star's target, 4096 per GPU)
+in ONE kernel launch, inputs already resident in HBM, cold start as
+KinoDynMP::set_warm_starts does.  Multi-GPU: one process per GPU, the batch is sharded
+(rank r solves problems [r*B, (r+1)*B)), no data-path collective (the solves are
+independent); RCCL only carries the timing/telemetry reductions.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with
+  roofline      HBM view of the ADMM kernel (algorithmic bytes per launch / measured kernel
+                time; the path is fp64-VALU/latency bound, so `valu` carries the meaningful
+                fraction) and
+  cpu_baseline  the CPU restatement of the reference algorithm (oracle/, "port") timed on
+                this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VALU_PEAK_TF = 78.6    # MI355X vector fp64 peak (spec)
+
+
+def flops_from_stats(stats, H, E=4):
+    """SURVEY.md 8d flop model: F-step ~90 flops per knot.foot, X-step ~250 flops per knot,
+    per FISTA iteration (retries counted as iterations)."""
+    it_f = stats[:, 1].sum() + stats[:, 3].sum()
+    it_x = stats[:, 2].sum() + stats[:, 4].sum()
+    return float(it_f) * 90.0 * E * H + float(it_x) * 250.0 * (H + 1)
+
+
+def cpu_baseline(config, H_iters, sample, maxit):
+    from bunmpc_amd import problems
+    from oracle import oracle_c
+    oracle_c.build()
+    cores = os.cpu_count() or 1
+    b = problems.make_batch(config, sample)
+    oracle_c.solve_batch(b.slice(0, min(cores, sample)), num_iters=H_iters, maxit=maxit, nthreads=cores)  # warm-up
+    t0 = time.perf_counter()
+    oracle_c.solve_batch(b, num_iters=H_iters, maxit=maxit, nthreads=cores)
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    oracle_c.solve_batch(b.slice(0, 4), num_iters=H_iters, maxit=maxit, nthreads=1)
+    lat = (time.perf_counter() - t1) / 4
+    return {"value": sample / dt, "unit": "solves/s", "cores": cores, "kind": "port",
+            "sample": "%d problems of the same workload, one solve per OpenMP thread over %d threads, "
+                      "strict restatement of the reference formulation (explicit sparse Hessian); "
+                      "not the reference binary (needs Eigen, absent)" % (sample, cores),
+            "single_core_ms_per_solve": lat * 1e3}
+
+
+def p50_latency(config, num_iters, reps=60):
+    """Batch-1 wall time of BiconvexMP.optimize through the drop-in class, incl. H2D of the
+    inputs and D2H of X/F/P."""
+    from bunmpc_amd import problems
+    from bunmpc_amd.biconvex_mpc_cpp import BiconvexMP
+    b = problems.make_batch(config, 1)
+    H, E = b.H, b.E
+    mp = BiconvexMP(b.m, H, E)
+    mp.set_rho(b.rho)
+    X0, F0, P0 = b.warm_start()
+    ts = []
+    for r in range(reps + 5):
+        for i in range(H):
+            mp.set_contact_plan(b.cnt_plan[0, i], b.dt[0, i])
+        mp.create_bound_constraints(b.bounds[0], 15.0, 15.0, 15.0)
+        mp.create_cost_X(b.W_X[0], b.W_X_ter[0], b.X_ter[0], b.X_nom[0])
+        mp.create_cost_F(b.W_F[0])
+        mp.set_warm_start_vars(X0[0], F0[0], P0[0])
+        mp.set_step_constants(2.25e6, 506.25)
+        t0 = time.perf_counter()
+        mp.optimize(b.x_init[0], num_iters)
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts[5:]) * 1e3)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096, help="problems per GPU")
+    ap.add_argument("--config", default="solo12_trot")
+    ap.add_argument("--admm-iters", type=int, default=10)
+    ap.add_argument("--maxit", type=int, default=150)
+    ap.add_argument("--cpu-sample", type=int, default=256)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback for the solve)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    if args.gpus != world and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    from bunmpc_amd import batch as bb
+    from bunmpc_amd import problems
+    B = args.batch
+    pb = problems.make_batch(args.config, B, first=rank * B)
+    db = bb.DeviceBatch(pb, device=dev, num_iters=args.admm_iters, maxit=args.maxit)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        db.solve()
+    sync()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        ev[s][0].record()
+        db.solve()
+        ev[s][1].record()
+    sync()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    res = db.results()
+    tele = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
+    counts = torch.tensor([float((res["stats"][:, 5] != 0).sum()), float(res["stats"][:, 1:3].sum()),
+                           flops_from_stats(res["stats"], pb.H)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tele, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    elapsed, kern_ms = float(tele[0]), float(tele[1])
+    total = B * world * args.steps
+
+    if rank == 0:
+        per_w = pb.W_X.shape[0] != 1
+        abytes = bb.algorithmic_bytes_per_solve(pb.H, pb.E, per_w) * B
+        achieved = abytes / (kern_ms * 1e-3) / 1e9
+        flops = float(counts[2]) / world  # per launch on one GPU
+        out = {
+            "metric": "MPC solves/sec (batch, whole node), Solo12 trot H=20, 10 ADMM iters, fp64",
+            "value": total / elapsed, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "%s H=%d B=%d/GPU admm_iters=%d fista_maxit=%d cold-start"
+                                   % (args.config, pb.H, B, args.admm_iters, args.maxit),
+                       "global_batch": B * world, "parallelism": "batch-shard x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "biconvex_admm_kernel", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": abytes,
+                         "valu": {"model_flops_per_launch": flops,
+                                  "achieved_tflops": flops / (kern_ms * 1e-3) / 1e12,
+                                  "peak_tflops": FP64_VALU_PEAK_TF,
+                                  "frac": flops / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF}},
+            "diverged": int(counts[0]), "fista_iters_per_solve": float(counts[1]) / (B * world),
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.config, args.admm_iters, args.cpu_sample, args.maxit)
+            out["speedup_vs_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["value"]
+        if world == 1 and not args.no_latency:
+            out["p50_latency_ms_batch1"] = p50_latency(args.config, args.admm_iters)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,124 @@
+"""ctypes binding of libbunmpc_hip.so (include/bunmpc.h).  There is no CPU fallback:
+if the library is missing and cannot be built, or a call needs a GPU that is not
+there, this raises."""
+import ctypes as C
+import os
+
+from . import build as _build
+
+OK, BAD_ARG, DIVERGED, DEVICE_ERROR = 0, 1, 2, 3
+L0_X, L0_F = 2.25e6, 506.25
+NSTATS = 6
+
+
+class BmpcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("bunmpc status %d: %s" % (code, msg))
+        self.code = code
+
+
+class Batch(C.Structure):
+    """bmpc_batch_t"""
+    _fields_ = ([("B", C.c_int), ("n_col", C.c_int), ("n_eff", C.c_int), ("raw", C.c_int),
+                 ("num_iters", C.c_int), ("maxit", C.c_int), ("cold_start", C.c_int),
+                 ("reserved_", C.c_int)] +
+                [(n, C.c_double) for n in ("m", "rho", "mu", "beta", "tol", "exit_tol")] +
+                [(n, C.c_void_p) for n in ("cnt_plan", "dt", "x_init", "W_X", "W_X_ter", "W_F",
+                                           "bounds", "X_nom", "X_ter")] +
+                [(n, C.c_long) for n in ("sW_X", "sW_X_ter", "sW_F", "sbounds")] +
+                [(n, C.c_void_p) for n in ("Qx", "qx", "lbx", "ubx", "Qf", "qf", "X", "F", "P",
+                                           "L_x", "L_f", "dyn_viol", "hist", "stats")])
+
+
+_lib = None
+
+_D = C.c_double
+_I = C.c_int
+_P = C.c_void_p
+
+_SIGS = {
+    "bmpc_abi_version": (_I, []),
+    "bmpc_last_error": (C.c_char_p, []),
+    "bmpc_device_count": (_I, [_P]),
+    "bmpc_set_device": (_I, [_I]),
+    "bmpc_selftest_lanes": (_I, []),
+    "bmpc_gait_create": (_P, [_D, _P, _P, _I, _D]),
+    "bmpc_gait_destroy": (None, [_P]),
+    "bmpc_gait_n_eff": (_I, [_P]),
+    "bmpc_gait_get_phase": (_I, [_P, _D, _I, _P]),
+    "bmpc_gait_get_phase_all": (_I, [_P, _D, _P]),
+    "bmpc_gait_get_phi": (_I, [_P, _D, _I, _P]),
+    "bmpc_gait_get_phi_all": (_I, [_P, _D, _P]),
+    "bmpc_gait_get_percent_in_phase": (_I, [_P, _D, _I, _P]),
+    "bmpc_gait_get_percent_in_phase_all": (_I, [_P, _D, _P]),
+    "bmpc_gait_get_contact_phase_plan": (_I, [_P, _I, _D, _D, _P]),
+    "bmpc_gait_set_step_height": (_I, [_P, _D]),
+    "bmpc_gait_set_stance_percent": (_I, [_P, _D, _D, _D, _D]),
+    "bmpc_biconvex_create": (_P, [_D, _I, _I]),
+    "bmpc_biconvex_destroy": (None, [_P]),
+    "bmpc_biconvex_n_col": (_I, [_P]),
+    "bmpc_biconvex_n_eff": (_I, [_P]),
+    "bmpc_biconvex_set_contact_plan": (_I, [_P, _P, _D]),
+    "bmpc_biconvex_set_rotation_matrix_f": (_I, [_P, _P]),
+    "bmpc_biconvex_return_A_x": (_I, [_P, _P, _P]),
+    "bmpc_biconvex_return_b_x": (_I, [_P, _P, _P]),
+    "bmpc_biconvex_return_A_f": (_I, [_P, _P, _P, _P]),
+    "bmpc_biconvex_return_b_f": (_I, [_P, _P, _P, _P]),
+    "bmpc_biconvex_set_cost_x": (_I, [_P, _P, _P]),
+    "bmpc_biconvex_set_cost_f": (_I, [_P, _P, _P]),
+    "bmpc_biconvex_create_cost_X": (_I, [_P, _P, _P, _P, _P]),
+    "bmpc_biconvex_create_cost_F": (_I, [_P, _P]),
+    "bmpc_biconvex_set_bounds_x": (_I, [_P, _P, _P]),
+    "bmpc_biconvex_set_bounds_f": (_I, [_P, _P, _P]),
+    "bmpc_biconvex_create_bound_constraints": (_I, [_P, _P, _I, _I, _D, _D, _D]),
+    "bmpc_biconvex_set_rho": (_I, [_P, _D]),
+    "bmpc_biconvex_return_opt_x": (_I, [_P, _P]),
+    "bmpc_biconvex_return_opt_f": (_I, [_P, _P]),
+    "bmpc_biconvex_return_opt_p": (_I, [_P, _P]),
+    "bmpc_biconvex_return_opt_com": (_I, [_P, _P]),
+    "bmpc_biconvex_return_opt_mom": (_I, [_P, _P]),
+    "bmpc_biconvex_set_warm_start_vars": (_I, [_P, _P, _P, _P]),
+    "bmpc_biconvex_optimize": (_I, [_P, _P, _I]),
+    "bmpc_biconvex_dyn_viol_hist_size": (_I, [_P]),
+    "bmpc_biconvex_return_dyn_viol_hist": (_I, [_P, _P]),
+    "bmpc_biconvex_collect_statistics": (_I, [_P]),
+    "bmpc_biconvex_get_step_constants": (_I, [_P, _P, _P]),
+    "bmpc_biconvex_set_step_constants": (_I, [_P, _D, _D]),
+    "bmpc_biconvex_last_stats": (_I, [_P, _P]),
+    "bmpc_biconvex_set_friction_coefficient": (_I, [_P, _D]),
+    "bmpc_biconvex_set_robot_mass": (_I, [_P, _D]),
+    "bmpc_batch_defaults": (None, [_P]),
+    "bmpc_biconvex_solve_batch_device": (_I, [_P, _P]),
+    "bmpc_biconvex_solve_batch_host": (_I, [_P]),
+    "bmpc_biconvex_kernel_name": (C.c_char_p, [_I, _I]),
+}
+
+
+def exported_symbols():
+    """Every symbol include/bunmpc.h declares (checked by the CPU tests)."""
+    return sorted(_SIGS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = _build.LIB
+        if not os.path.exists(path) or (_build.is_stale() and os.path.exists(_build.HIPCC)):
+            path = _build.build()
+        handle = C.CDLL(path)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code):
+    if code != OK:
+        raise BmpcError(code, lib().bmpc_last_error().decode())
+    return code
+
+
+def last_error():
+    return lib().bmpc_last_error().decode()

@@ -1,0 +1,64 @@
+// Internal (not part of the C-ABI): argument block shared by the host launcher
+// (bunmpc_capi.hip) and the batched centroidal ADMM kernel (biconvex_admm.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace bunmpc {
+
+// Solver constants (reference defaults: biconvex.hpp:146-160, fista.hpp:52-60).
+struct SolverConsts {
+    double m;         // robot mass
+    double rho;       // ADMM penalty
+    double mu;        // friction coefficient of the "SoC" projection
+    double beta;      // backtracking growth
+    double tol;       // FISTA exit: ||y+ - y|| < tol
+    double exit_tol;  // ADMM exit: ||A_f X - b_f|| < exit_tol
+    int maxit;        // FISTA iteration cap
+    int num_iters;    // ADMM iteration cap
+};
+
+// One batch of B independent BiConvexMP::optimize calls.  All pointers are DEVICE
+// pointers.  Layout (row-major, batch outermost, then knot, then component):
+//   cnt_plan [B][H][E][4]   rows [flag, x, y, z]            (set_contact_plan)
+//   dt       [B][H]
+//   x_init   [B][9]
+// cost / bound description, one of two forms:
+//   harness form (raw == 0): what create_cost_X / create_cost_F /
+//     create_bound_constraints receive; the kernel applies those formulas itself.
+//       W_X [.][9H], W_X_ter [.][9], W_F [.][3EH], bounds [.][H][6]  (batch stride 0 = shared)
+//       X_nom [B][9H], X_ter [B][9]
+//   raw form (raw == 1): what set_cost_x / set_cost_f / set_bounds_x leave behind
+//       Qx, qx, lbx, ubx [B][9(H+1)] (Qx = diagonal), Qf [B][3EH], qf [B][3EH] or null
+// state, in = warm start (set_warm_start_vars), out = last iterates:
+//   X [B][9(H+1)], F [B][3EH], P [B][9(H+1)], L_x [B], L_f [B]
+// telemetry: dyn_viol [B] (last ||A_f X - b_f||), hist [B][num_iters] or null,
+//   stats [B][6] = {admm iters, sum F-FISTA iters, sum X-FISTA iters, F retries,
+//                   X retries, status (0 ok, 2 NaN)}
+struct BatchArgs {
+    int B, H, raw, cold_start;
+    double L0_x, L0_f;
+    SolverConsts c;
+    const double *cnt_plan, *dt, *x_init;
+    const double *W_X, *W_X_ter, *W_F, *bounds, *X_nom, *X_ter;
+    long sW_X, sW_X_ter, sW_F, sbounds;
+    const double *Qx, *qx, *lbx, *ubx, *Qf, *qf;
+    double *X, *F, *P, *L_x, *L_f;
+    double *dyn_viol, *hist;
+    int *stats;
+};
+
+constexpr int kStats = 6;
+constexpr int kMaxKnots = 64;  // H + 1 <= 64: one knot per lane, one problem per <=64 lanes
+
+// Launch the batched ADMM kernel on `stream`.  Returns hipSuccess or the launch error;
+// hipErrorInvalidValue for unsupported shapes (n_eff != 4, H + 1 > 64).
+hipError_t launch_biconvex_admm(const BatchArgs &a, int n_eff, hipStream_t stream);
+
+// Lane-exchange self test (DPP shifts and segment sums used by the kernel).
+// out must hold 6*64 doubles.
+hipError_t launch_lane_selftest(const double *in, double *out, hipStream_t stream);
+
+// Name of the kernel symbol for a given H (for profiling / bench reports).
+const char *biconvex_kernel_name(int H, int raw);
+
+}  // namespace bunmpc
