@@ -40,11 +40,23 @@ def flops_from_stats(stats, H, E=4):
     return float(it_f) * 90.0 * E * H + float(it_x) * 250.0 * (H + 1)
 
 
+def host_cores():
+    """CPUs this process may actually use: affinity mask capped by the cgroup quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(config, H_iters, sample, maxit):
     from bunmpc_amd import problems
     from oracle import oracle_c
     oracle_c.build()
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     b = problems.make_batch(config, sample)
     oracle_c.solve_batch(b.slice(0, min(cores, sample)), num_iters=H_iters, maxit=maxit, nthreads=cores)  # warm-up
     t0 = time.perf_counter()

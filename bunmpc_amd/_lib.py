@@ -38,6 +38,7 @@ _P = C.c_void_p
 
 _SIGS = {
     "bmpc_abi_version": (_I, []),
+    "bmpc_batch_struct_size": (_I, []),
     "bmpc_last_error": (C.c_char_p, []),
     "bmpc_device_count": (_I, [_P]),
     "bmpc_set_device": (_I, [_I]),
@@ -99,9 +100,23 @@ def exported_symbols():
     return sorted(_SIGS)
 
 
+def _preload_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's).  Two HIP
+    runtimes in one process do not work (the second sees no device), so when torch is installed
+    bind this library to torch's copy whichever of the two is imported first."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     global _lib
     if _lib is None:
+        _preload_hip_runtime()
         path = _build.LIB
         if not os.path.exists(path) or (_build.is_stale() and os.path.exists(_build.HIPCC)):
             path = _build.build()
@@ -110,6 +125,8 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
+        if handle.bmpc_batch_struct_size() != C.sizeof(Batch):
+            raise ImportError("bmpc_batch_t layout differs between include/bunmpc.h and bunmpc_amd/_lib.py")
         _lib = handle
     return _lib
 

@@ -127,6 +127,7 @@ struct bmpc_biconvex {
 extern "C" {
 
 int bmpc_abi_version(void) { return 1; }
+int bmpc_batch_struct_size(void) { return (int)sizeof(bmpc_batch_t); }
 const char *bmpc_last_error(void) { return g_err.c_str(); }
 
 int bmpc_device_count(int *count) {

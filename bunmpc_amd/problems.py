@@ -209,6 +209,18 @@ class Batch:
         P = np.zeros((self.B, 9 * (self.H + 1)))
         return X, F, P
 
+    def take(self, idx):
+        """sub-batch of the problems listed in idx"""
+        idx = np.asarray(idx)
+
+        def s(a):
+            return a if a is None or a.shape[0] == 1 else a[idx]
+        return Batch(self.name, len(idx), self.H, self.E, self.m, self.rho, self.cnt_plan[idx],
+                     self.dt[idx], self.x_init[idx], self.X_nom[idx], self.X_ter[idx],
+                     s(self.W_X), s(self.W_X_ter), s(self.W_F), s(self.bounds),
+                     None if self.swing_time is None else self.swing_time[idx],
+                     None if self.gait_id is None else self.gait_id[idx], self.mu, dict(self.meta))
+
     def slice(self, lo, hi):
         def s(a):
             return a if a is None or a.shape[0] == 1 else a[lo:hi]

@@ -28,6 +28,7 @@ extern "C" {
 
 /* library / device ----------------------------------------------------------- */
 int bmpc_abi_version(void);
+int bmpc_batch_struct_size(void);            /* sizeof(bmpc_batch_t), to catch binding drift  */
 const char *bmpc_last_error(void);           /* thread-local text of the last failure   */
 int bmpc_device_count(int *count);           /* hipGetDeviceCount                        */
 int bmpc_set_device(int device);             /* hipSetDevice for the calling thread      */
