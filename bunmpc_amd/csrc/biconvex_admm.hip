@@ -49,8 +49,9 @@ constexpr int DPP_WAVE_SHR1 = 0x138;    // lane i <- lane i-1
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    // bound_ctrl:1 -- a lane without a source lane reads 0, so no destination pre-initialisation
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 // value held by the previous / next knot's lane (0 at the wave ends)
@@ -85,11 +86,41 @@ __device__ __forceinline__ double seg_sum(double v) {
 
 __device__ __forceinline__ double ldz(const double *p, long i, bool ok) { return ok ? p[i] : 0.0; }
 
+// v where m is all ones, +0.0 where m is 0 -- two v_and_b32, no branch, and (unlike a multiply by
+// 0/1) it also wipes NaN/inf, which keeps a diverged problem from leaking into its wave-mate
+__device__ __forceinline__ double keep_if(double v, int m) {
+    return __hiloint2double(__double2hiint(v) & m, __double2loint(v) & m);
+}
+
+// a / b to ~1 ulp without the IEEE division sequence: v_rcp_f64 (2^-26 or better) + two Newton
+// steps + one residual correction.  Used only inside the cone branch of the projection.
+__device__ __forceinline__ double fast_div(double a, double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+
 constexpr double kGravity = 9.81;  // centroidal.cpp:63
 
 // ------------------------------------------------------------------------------
-template <int LPP, int E, bool RAW>
+// Per-iteration algebra (what differs from the reference's formulation, all of it exact
+// algebra on the same quadratic):
+//   * acceptance test.  fista.cpp:16 tests  f(y+) - f(y) > g.d + (L/2)|d|^2 ; for the quadratic
+//     f = y'Qy + q'y + rho|Ay - b + P|^2 that difference is  g.d + d'Qd + rho|A d|^2  identically,
+//     and A d = (A y+ + bPk) - (A y + bPk) is at hand, so the test becomes
+//     d'Qd + rho|A d|^2 > (L/2)|d|^2 : two segment sums instead of three, no cancellation.
+//   * x_init rows.  A_f's last nine rows are the identity on X_0 (centroidal.hpp:22-27), i.e. the
+//     term rho|X_0 - x_init + P_H|^2: a diagonal quadratic in X_0.  Lane 0 adds rho to its Q and
+//     2 rho (P_H - x_init) to its q instead of every lane carrying nine extra residual rows.
+//   * momentum coefficients (t_k - 1)/t_{k+1} (fista.cpp:34-35) depend on the iteration index
+//     only; each wave tabulates them once in LDS.
+//   * a problem that finishes (|d| < tol or maxit) has its iterate latched into `fin` registers
+//     at that moment; the loop body itself carries no per-lane freeze selects.
+template <int LPP, int E, bool RAW, bool HASQF>
 __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
+    extern __shared__ double cmtab[];   // [maxit]
     constexpr int NF = 3 * E;           // force variables per knot
     constexpr int NB = RAW ? 9 : 3;     // bounded components per knot
     const int lane = threadIdx.x & 63;
@@ -111,22 +142,31 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
 
     double *Xg = a.X + pb * nx + 9L * t;
     double *Fg = a.F + pb * nf + (long)NF * t;
+    double *Pg = a.P + pb * nx + 9L * t;
+    double *PIg = a.P + pb * nx + 9L * H;
 
-    // ---- per-knot constants that live through the whole solve
+    {   // momentum table: t+ = 1 + sqrt(1 + 4 t^2)/2 (sic, fista.cpp:34), c = (t - 1)/t+
+        double tk = 1.0;
+        for (int i = 0; i < maxit; ++i) {
+            const double tk1 = 1.0 + sqrt(1.0 + 4.0 * tk * tk) * 0.5;
+            if (lane == 0) cmtab[i] = (tk - 1.0) / tk1;
+            tk = tk1;
+        }
+        __syncthreads();
+    }
+
     const double dt = ldz(a.dt, pb * H + t, rvalid);
     const double dtp = from_prev(dt);  // dt of knot t-1 (0 for t == 0: previous lane is a dead/terminal lane)
     const bool cold = a.cold_start != 0;
-    double P[9], PI[9], xin[9];
-    UNROLL for (int l = 0; l < 9; ++l) {
-        P[l] = cold ? 0.0 : ldz(a.P, pb * nx + 9L * t + l, rvalid);
-        PI[l] = cold ? 0.0 : ldz(a.P, pb * nx + 9L * H + l, l0);
-        xin[l] = ldz(a.x_init, pb * 9 + l, l0);
-    }
     double L_x = cold ? a.L0_x : (pvalid ? a.L_x[pb] : 1.0);
     double L_f = cold ? a.L0_f : (pvalid ? a.L_f[pb] : 1.0);
-    if (cold) {  // KinoDynMP::set_warm_starts (kino_dyn.cpp:83-99): X = tile(x_init), F = 0 (P = 0 above)
+    if (cold) {  // KinoDynMP::set_warm_starts (kino_dyn.cpp:83-99): X = tile(x_init), F = 0, P = 0
         if (kvalid) { UNROLL for (int l = 0; l < 9; ++l) Xg[l] = a.x_init[pb * 9 + l]; }
-        if (rvalid) { UNROLL for (int j = 0; j < NF; ++j) Fg[j] = 0.0; }
+        if (rvalid) {
+            UNROLL for (int j = 0; j < NF; ++j) Fg[j] = 0.0;
+            UNROLL for (int l = 0; l < 9; ++l) Pg[l] = 0.0;
+        }
+        if (l0) { UNROLL for (int l = 0; l < 9; ++l) PIg[l] = 0.0; }
     }
     bool alive = pvalid;
     int n_admm = 0, it_f = 0, it_x = 0, bt_f = 0, bt_x = 0, status = 0;
@@ -134,16 +174,17 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
 
     for (int it = 0; it < a.c.num_iters; ++it) {
         if (!__any(alive)) break;
-        // contact data of this knot: flags c_n, positions r_n  (centroidal.cpp:39-49)
-        double c[E], r[E][3];
-        UNROLL for (int n = 0; n < E; ++n) {
-            const long o = ((pb * H + t) * E + n) * 4;
-            c[n] = ldz(a.cnt_plan, o, rvalid);
-            UNROLL for (int k = 0; k < 3; ++k) r[n][k] = ldz(a.cnt_plan, o + 1 + k, rvalid);
-        }
+        // contact data of this knot: flags c_n, positions r_n  (centroidal.cpp:39-49); re-read in
+        // each phase (L2-resident) rather than held in registers across the FISTA loops
+        const double *cg = a.cnt_plan + (pb * H + t) * E * 4;
 
         // =================================================================== F step
         {
+            double c[E], r[E][3];
+            UNROLL for (int n = 0; n < E; ++n) {
+                c[n] = ldz(cg, 4 * n, rvalid);
+                UNROLL for (int k = 0; k < 3; ++k) r[n][k] = ldz(cg, 4 * n + 1 + k, rvalid);
+            }
             double X[9];
             UNROLL for (int l = 0; l < 9; ++l) X[l] = kvalid ? Xg[l] : 0.0;
             // bPk rows 9t+3..8 = -b_x + P, b_x = X_{t+1} - X_t (+g dt)   (centroidal.cpp:60-65)
@@ -152,7 +193,7 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
                 const double xn = from_next(X[3 + k]);
                 double bx = xn - X[3 + k];
                 if (k == 2) bx += kGravity * dt;
-                bpk[k] = rvalid ? (-bx + P[3 + k]) : 0.0;
+                bpk[k] = rvalid ? (-bx + Pg[3 + k]) : 0.0;
             }
             // A_x entries of this knot (centroidal.cpp:67-81)
             double an[E], sp[E][3];
@@ -160,15 +201,12 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
                 an[n] = c[n] * (dt / m);
                 UNROLL for (int k = 0; k < 3; ++k) sp[n][k] = c[n] * (X[k] - r[n][k]) * dt;
             }
-            double wf2[NF], qf[NF];
+            double wf[NF], wf2[NF], qf[HASQF ? NF : 1];
             UNROLL for (int j = 0; j < NF; ++j) {
-                if (RAW) {
-                    wf2[j] = 2.0 * ldz(a.Qf, pb * nf + (long)NF * t + j, rvalid);
-                    qf[j] = a.qf ? ldz(a.qf, pb * nf + (long)NF * t + j, rvalid) : 0.0;
-                } else {
-                    wf2[j] = 2.0 * ldz(a.W_F, pb * a.sW_F + (long)NF * t + j, rvalid);
-                    qf[j] = 0.0;
-                }
+                wf[j] = RAW ? ldz(a.Qf, pb * nf + (long)NF * t + j, rvalid)
+                            : ldz(a.W_F, pb * a.sW_F + (long)NF * t + j, rvalid);
+                wf2[j] = 2.0 * wf[j];
+                if (HASQF) qf[j] = ldz(a.qf, pb * nf + (long)NF * t + j, rvalid);
             }
             // u = A v + bPk on rows 9t+3..8
             auto applyA = [&](const double (&v)[NF], double (&u)[6]) {
@@ -184,87 +222,112 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
                 u[3] = s3 + bpk[3]; u[4] = s4 + bpk[4]; u[5] = s5 + bpk[5];
             };
 
-            double x[NF], y[NF], g[NF], y1[NF];
-            double ry[6], rx[6], r1[6];
-            UNROLL for (int j = 0; j < NF; ++j) { x[j] = rvalid ? Fg[j] : 0.0; y[j] = x[j]; }
+            // FISTA state.  x lives in two buffers (xa/xb, A-images ra/rb) whose roles swap every
+            // iteration, so "x_k = x_k_1" (fista.cpp:37) costs no register moves.
+            double xa[NF], xb[NF], y[NF], ra[6], rb[6], ry[6];
+            UNROLL for (int j = 0; j < NF; ++j) { xa[j] = rvalid ? Fg[j] : 0.0; y[j] = xa[j]; }
             applyA(y, ry);
-            UNROLL for (int k = 0; k < 6; ++k) rx[k] = ry[k];
-            const double imu = 1.0 / (mu * mu + 1.0);
-            double tk = 1.0;
+            UNROLL for (int k = 0; k < 6; ++k) ra[k] = ry[k];
+            const double mu2 = mu * mu, imu = 1.0 / (mu * mu + 1.0);
+            const double tol2 = tol * tol;
+            double invL = 1.0 / L_f;
             bool act = alive;
-            for (int i = 0; i < maxit; ++i) {
-                if (!__any(act)) break;
-                // gradient 2 Q y + q + 2 rho A^T (A y + bPk)          (problem.cpp:36-38,54-56)
+            // one FISTA iteration: reads x from xo/ro, leaves x_{k+1} in xn/rn, advances y/ry
+            auto iterate = [&](const double (&xo)[NF], const double (&ro)[6], double (&xn)[NF], double (&rn)[6], int i) {
+                const double cm = cmtab[i];
+                // g = 2 Q y + q + 2 rho A^T (A y + bPk)          (problem.cpp:36-38,54-56)
+                double gs[NF];
                 UNROLL for (int n = 0; n < E; ++n) {
                     const double zx = an[n] * ry[0] - sp[n][2] * ry[4] + sp[n][1] * ry[5];
                     const double zy = an[n] * ry[1] + sp[n][2] * ry[3] - sp[n][0] * ry[5];
                     const double zz = an[n] * ry[2] - sp[n][1] * ry[3] + sp[n][0] * ry[4];
-                    g[3 * n] = wf2[3 * n] * y[3 * n] + qf[3 * n] + rho2 * zx;
-                    g[3 * n + 1] = wf2[3 * n + 1] * y[3 * n + 1] + qf[3 * n + 1] + rho2 * zy;
-                    g[3 * n + 2] = wf2[3 * n + 2] * y[3 * n + 2] + qf[3 * n + 2] + rho2 * zz;
+                    gs[3 * n] = fma(wf2[3 * n], y[3 * n], rho2 * zx);
+                    gs[3 * n + 1] = fma(wf2[3 * n + 1], y[3 * n + 1], rho2 * zy);
+                    gs[3 * n + 2] = fma(wf2[3 * n + 2], y[3 * n + 2], rho2 * zz);
+                    if (HASQF) { gs[3 * n] += qf[3 * n]; gs[3 * n + 1] += qf[3 * n + 1]; gs[3 * n + 2] += qf[3 * n + 2]; }
                 }
-                double Gn;
+                bool done;
                 bool pend = act;
-                do {  // backtracking (fista.cpp:8-26); segments that accepted recompute the same values
-                    const double invL = 1.0 / L_f;
+                for (;;) {  // backtracking (fista.cpp:8-26); segments that accepted recompute the same values
                     // "SoC" projection exactly as fista.cpp:52-70 writes it
+                    bool anycone = false;
+                    double fr[NF];
+                    UNROLL for (int j = 0; j < NF; ++j) fr[j] = fma(-gs[j], invL, y[j]);
                     UNROLL for (int n = 0; n < E; ++n) {
-                        double fx = y[3 * n] - g[3 * n] * invL;
-                        double fy = y[3 * n + 1] - g[3 * n + 1] * invL;
-                        double fz = y[3 * n + 2] - g[3 * n + 2] * invL;
-                        const double s = fx * fx + fy * fy;
-                        const double z = fz;
-                        const bool zero = (s * mu < -z) || (z < 0);
-                        const bool cone = !zero && (s > mu * z);
-                        const double k = ((mu * mu) * s + (mu * z)) / (((mu * mu) + 1.0) * s);
-                        const double zc = (mu * s + z) * imu;
-                        fx = zero ? 0.0 : (cone ? fx * k : fx);
-                        fy = zero ? 0.0 : (cone ? fy * k : fy);
-                        fz = zero ? 0.0 : (cone ? zc : fz);
-                        y1[3 * n] = fx; y1[3 * n + 1] = fy; y1[3 * n + 2] = fz;
+                        const double s = fma(fr[3 * n], fr[3 * n], fr[3 * n + 1] * fr[3 * n + 1]);
+                        const double fz = fr[3 * n + 2];
+                        const bool zero = (s * mu < -fz) || (fz < 0);
+                        anycone = anycone || (!zero && (s > mu * fz));
+                        xn[3 * n] = zero ? 0.0 : fr[3 * n];
+                        xn[3 * n + 1] = zero ? 0.0 : fr[3 * n + 1];
+                        xn[3 * n + 2] = zero ? 0.0 : fz;
                     }
-                    applyA(y1, r1);
-                    double g2 = 0, gd = 0, od = 0, n1 = 0, n0 = 0;
+                    if (__any(anycone)) {   // cone branch (fista.cpp:64-68); skipped while no lane needs it
+                        UNROLL for (int n = 0; n < E; ++n) {
+                            const double s = fma(fr[3 * n], fr[3 * n], fr[3 * n + 1] * fr[3 * n + 1]);
+                            const double fz = fr[3 * n + 2];
+                            const bool zero = (s * mu < -fz) || (fz < 0);
+                            const bool cone = !zero && (s > mu * fz);
+                            const double k = fast_div(fma(mu2, s, mu * fz), (mu2 + 1.0) * s);
+                            xn[3 * n] = cone ? fr[3 * n] * k : xn[3 * n];
+                            xn[3 * n + 1] = cone ? fr[3 * n + 1] * k : xn[3 * n + 1];
+                            xn[3 * n + 2] = cone ? fma(mu, s, fz) * imu : xn[3 * n + 2];
+                        }
+                    }
+                    applyA(xn, rn);
+                    double g2 = 0, cv = 0, e2 = 0;
                     UNROLL for (int j = 0; j < NF; ++j) {
-                        const double d = y1[j] - y[j];
-                        g2 += d * d;
-                        gd += g[j] * d;
-                        od += ((y1[j] + y[j]) * (0.5 * wf2[j]) + qf[j]) * d;
+                        const double d = xn[j] - y[j];
+                        g2 = fma(d, d, g2);
+                        cv = fma(wf[j] * d, d, cv);
                     }
-                    UNROLL for (int k = 0; k < 6; ++k) { n1 += r1[k] * r1[k]; n0 += ry[k] * ry[k]; }
-                    od += rho * (n1 - n0);
+                    UNROLL for (int k = 0; k < 6; ++k) { const double e = rn[k] - ry[k]; e2 = fma(e, e, e2); }
+                    cv = fma(rho, e2, cv);
                     g2 = seg_sum<LPP>(g2);
-                    gd = seg_sum<LPP>(gd);
-                    od = seg_sum<LPP>(od);
-                    Gn = sqrt(g2);
-                    const bool bt = pend && (od > gd + (L_f * 0.5) * (Gn * Gn));
-                    if (bt) { L_f *= beta; ++bt_f; }
+                    cv = seg_sum<LPP>(cv);
+                    // fista.cpp:14-17: G = sqrt(g2); retry if cv > (L/2) G*G; done if G < tol.  G*G and g2
+                    // differ by a few ulp, so outside a 1e-14 relative band the sqrt cannot change either
+                    // decision; inside it the reference expression is evaluated as written.
+                    const double rhs = (L_f * 0.5) * g2;
+                    bool bt = cv > rhs;
+                    done = g2 < tol2;
+                    const bool edge = (fabs(cv - rhs) <= 1e-14 * rhs) || (fabs(g2 - tol2) <= 1e-14 * tol2);
+                    if (__any(edge)) {
+                        const double Gn = sqrt(g2);
+                        bt = cv > (L_f * 0.5) * (Gn * Gn);
+                        done = Gn < tol;
+                    }
+                    bt = bt && pend;
                     pend = bt;
-                } while (__any(pend));
+                    if (!__any(bt)) break;
+                    if (bt) { L_f *= beta; ++bt_f; }
+                    invL = 1.0 / L_f;
+                }
+                const bool last = act && (done || i == maxit - 1);
+                if (__any(last)) {   // x_k of a finishing problem goes straight to its output block
+                    if (last && rvalid) { UNROLL for (int j = 0; j < NF; ++j) Fg[j] = xn[j]; }
+                }
                 // momentum (fista.cpp:33-47); A-images follow by linearity
-                const double tk1 = 1.0 + sqrt(1.0 + 4.0 * tk * tk) * 0.5;  // sic
-                const double cm = (tk - 1.0) / tk1;
-                const bool done = Gn < tol;
-                const bool adv = act && !done;
-                UNROLL for (int j = 0; j < NF; ++j) {
-                    const double yn = y1[j] + cm * (y1[j] - x[j]);
-                    x[j] = act ? y1[j] : x[j];
-                    y[j] = adv ? yn : y[j];
-                }
-                UNROLL for (int k = 0; k < 6; ++k) {
-                    const double rn = r1[k] + cm * (r1[k] - rx[k]);
-                    rx[k] = act ? r1[k] : rx[k];
-                    ry[k] = adv ? rn : ry[k];
-                }
-                tk = adv ? tk1 : tk;
+                UNROLL for (int j = 0; j < NF; ++j) y[j] = fma(cm, xn[j] - xo[j], xn[j]);
+                UNROLL for (int k = 0; k < 6; ++k) ry[k] = fma(cm, rn[k] - ro[k], rn[k]);
                 it_f += act ? 1 : 0;
-                act = adv;
+                act = act && !done;
+            };
+            for (int i = 0; i < maxit; i += 2) {
+                if (!__any(act)) break;
+                iterate(xa, ra, xb, rb, i);
+                if (i + 1 >= maxit || !__any(act)) break;
+                iterate(xb, rb, xa, ra, i + 1);
             }
-            if (rvalid) { UNROLL for (int j = 0; j < NF; ++j) Fg[j] = x[j]; }
         }
 
         // =================================================================== X step
         {
+            double c[E], r[E][3];
+            UNROLL for (int n = 0; n < E; ++n) {
+                c[n] = ldz(cg, 4 * n, rvalid);
+                UNROLL for (int k = 0; k < 3; ++k) r[n][k] = ldz(cg, 4 * n + 1 + k, rvalid);
+            }
             // A_f / b_f entries of this knot from the new forces (centroidal.cpp:86-127)
             double SX = 0, SY = 0, SZ = 0, bf[9];
             {
@@ -282,16 +345,13 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
                 bf[3] = b3; bf[4] = b4; bf[5] = b5 + kGravity * dt;
                 bf[6] = b6; bf[7] = b7; bf[8] = b8;
             }
-            double bpk[9], bpi[9];
-            UNROLL for (int l = 0; l < 9; ++l) {
-                bpk[l] = rvalid ? (-bf[l] + P[l]) : 0.0;
-                bpi[l] = l0 ? (-xin[l] + PI[l]) : 0.0;
-            }
+            double bpk[9];
+            UNROLL for (int l = 0; l < 9; ++l) bpk[l] = rvalid ? (-bf[l] + Pg[l]) : 0.0;
             // cost and bounds of this knot
-            double q2[9], q[9], lb[NB], ub[NB];
+            double qd[9], q[9], lb[NB], ub[NB];
             if (RAW) {
                 UNROLL for (int l = 0; l < 9; ++l) {
-                    q2[l] = 2.0 * ldz(a.Qx, pb * nx + 9L * t + l, kvalid);
+                    qd[l] = ldz(a.Qx, pb * nx + 9L * t + l, kvalid);
                     q[l] = ldz(a.qx, pb * nx + 9L * t + l, kvalid);
                 }
                 UNROLL for (int l = 0; l < NB; ++l) {
@@ -305,7 +365,7 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
                                             : (kvalid ? a.W_X_ter[pb * a.sW_X_ter + l] : 0.0);
                     const double xr = rvalid ? a.X_nom[pb * 9L * H + 9L * t + l]
                                              : (kvalid ? a.X_ter[pb * 9 + l] : 0.0);
-                    q2[l] = 2.0 * w;
+                    qd[l] = w;
                     q[l] = -2.0 * (xr * w);
                 }
                 // create_bound_constraints (biconvex.cpp:27-55): CoM box around the feet
@@ -321,6 +381,19 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
                     ub[k] = bounded ? mn + bhi : INFINITY;
                 }
             }
+            // x_init rows folded into lane 0's diagonal cost:  rho |X_0 + (P_H - x_init)|^2
+            double qd2[9];
+            UNROLL for (int l = 0; l < 9; ++l) {
+                const double bpi = l0 ? (PIg[l] - a.x_init[pb * 9 + l]) : 0.0;
+                qd[l] += l0 ? rho : 0.0;
+                q[l] += rho2 * bpi;
+                qd2[l] = 2.0 * qd[l];
+            }
+            UNROLL for (int l = 0; l < NB; ++l) {   // quieted once, so the clamp is a bare min/max pair
+                lb[l] = __builtin_canonicalize(lb[l]);
+                ub[l] = __builtin_canonicalize(ub[l]);
+            }
+            const int rmask = rvalid ? -1 : 0;      // row-block mask: lanes t >= H own no dynamics rows
             // u = A_f v + bPk on row-block t; vn = v of knot t+1
             auto applyA = [&](const double (&v)[9], double (&u)[9]) {
                 double vn[9];
@@ -331,93 +404,99 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
                 w[6] += SY * v[2] - SZ * v[1];
                 w[7] += SZ * v[0] - SX * v[2];
                 w[8] += SX * v[1] - SY * v[0];
-                UNROLL for (int l = 0; l < 9; ++l) u[l] = rvalid ? (w[l] + bpk[l]) : 0.0;
+                UNROLL for (int l = 0; l < 9; ++l) u[l] = keep_if(w[l] + bpk[l], rmask);
             };
 
-            double x[9], y[9], g[9], y1[9], ry[9], rx[9], r1[9];
-            UNROLL for (int l = 0; l < 9; ++l) { x[l] = kvalid ? Xg[l] : 0.0; y[l] = x[l]; }
+            double xa[9], xb[9], y[9], ra[9], rb[9], ry[9];
+            UNROLL for (int l = 0; l < 9; ++l) { xa[l] = kvalid ? Xg[l] : 0.0; y[l] = xa[l]; }
             applyA(y, ry);
-            UNROLL for (int l = 0; l < 9; ++l) rx[l] = ry[l];
-            double tk = 1.0;
+            UNROLL for (int l = 0; l < 9; ++l) ra[l] = ry[l];
+            const double tol2 = tol * tol;
+            double invL = 1.0 / L_x;
             bool act = alive;
-            for (int i = 0; i < maxit; ++i) {
-                if (!__any(act)) break;
+            auto iterate = [&](const double (&xo)[9], const double (&ro)[9], double (&xn)[9], double (&rn)[9], int i) {
+                const double cm = cmtab[i];
+                double gs[9];
                 {   // gradient 2 Q y + q + 2 rho A_f^T (A_f y + bPk)
                     double z[9], wp[9];
                     UNROLL for (int l = 0; l < 9; ++l) wp[l] = from_prev(ry[l]);  // row-block t-1 (0 for t == 0)
                     UNROLL for (int l = 0; l < 9; ++l) z[l] = ry[l] - wp[l];
-                    UNROLL for (int k = 0; k < 3; ++k) z[3 + k] += dtp * wp[k];
+                    UNROLL for (int k = 0; k < 3; ++k) z[3 + k] = fma(dtp, wp[k], z[3 + k]);
                     z[0] += SZ * ry[7] - SY * ry[8];
                     z[1] += SX * ry[8] - SZ * ry[6];
                     z[2] += SY * ry[6] - SX * ry[7];
-                    UNROLL for (int l = 0; l < 9; ++l) {
-                        const double wi = l0 ? (y[l] + bpi[l]) : 0.0;   // x_init rows
-                        g[l] = q2[l] * y[l] + q[l] + rho2 * (z[l] + wi);
-                    }
+                    UNROLL for (int l = 0; l < 9; ++l) gs[l] = fma(qd2[l], y[l], fma(rho2, z[l], q[l]));
                 }
-                double Gn;
+                bool done;
                 bool pend = act;
-                do {
-                    const double invL = 1.0 / L_x;
+                for (;;) {
                     UNROLL for (int l = 0; l < 9; ++l) {
-                        double v = y[l] - g[l] * invL;
+                        double v = fma(-gs[l], invL, y[l]);
                         if (l < NB) v = fmax(fmin(v, ub[l]), lb[l]);   // fista.cpp:10
-                        y1[l] = v;
+                        xn[l] = v;
                     }
-                    applyA(y1, r1);
-                    double g2 = 0, gd = 0, od = 0, n1 = 0, n0 = 0;
+                    applyA(xn, rn);
+                    double g2 = 0, cv = 0, e2 = 0;
                     UNROLL for (int l = 0; l < 9; ++l) {
-                        const double d = y1[l] - y[l];
-                        g2 += d * d;
-                        gd += g[l] * d;
-                        od += ((y1[l] + y[l]) * (0.5 * q2[l]) + q[l]) * d;
-                        n1 += r1[l] * r1[l];
-                        n0 += ry[l] * ry[l];
-                        const double i1 = l0 ? (y1[l] + bpi[l]) : 0.0, i0 = l0 ? (y[l] + bpi[l]) : 0.0;
-                        n1 += i1 * i1;
-                        n0 += i0 * i0;
+                        const double d = xn[l] - y[l];
+                        const double e = rn[l] - ry[l];
+                        g2 = fma(d, d, g2);
+                        cv = fma(qd[l] * d, d, cv);
+                        e2 = fma(e, e, e2);
                     }
-                    od += rho * (n1 - n0);
+                    cv = fma(rho, e2, cv);
                     g2 = seg_sum<LPP>(g2);
-                    gd = seg_sum<LPP>(gd);
-                    od = seg_sum<LPP>(od);
-                    Gn = sqrt(g2);
-                    const bool bt = pend && (od > gd + (L_x * 0.5) * (Gn * Gn));
-                    if (bt) { L_x *= beta; ++bt_x; }
+                    cv = seg_sum<LPP>(cv);
+                    const double rhs = (L_x * 0.5) * g2;   // see the force loop for the sqrt-free form
+                    bool bt = cv > rhs;
+                    done = g2 < tol2;
+                    const bool edge = (fabs(cv - rhs) <= 1e-14 * rhs) || (fabs(g2 - tol2) <= 1e-14 * tol2);
+                    if (__any(edge)) {
+                        const double Gn = sqrt(g2);
+                        bt = cv > (L_x * 0.5) * (Gn * Gn);
+                        done = Gn < tol;
+                    }
+                    bt = bt && pend;
                     pend = bt;
-                } while (__any(pend));
-                const double tk1 = 1.0 + sqrt(1.0 + 4.0 * tk * tk) * 0.5;  // sic
-                const double cm = (tk - 1.0) / tk1;
-                const bool done = Gn < tol;
-                const bool adv = act && !done;
-                UNROLL for (int l = 0; l < 9; ++l) {
-                    const double yn = y1[l] + cm * (y1[l] - x[l]);
-                    const double rn = r1[l] + cm * (r1[l] - rx[l]);
-                    x[l] = act ? y1[l] : x[l];
-                    rx[l] = act ? r1[l] : rx[l];
-                    y[l] = adv ? yn : y[l];
-                    ry[l] = adv ? rn : ry[l];
+                    if (!__any(bt)) break;
+                    if (bt) { L_x *= beta; ++bt_x; }
+                    invL = 1.0 / L_x;
                 }
-                tk = adv ? tk1 : tk;
+                const bool last = act && (done || i == maxit - 1);
+                if (__any(last)) {
+                    if (last && kvalid) { UNROLL for (int l = 0; l < 9; ++l) Xg[l] = xn[l]; }
+                }
+                UNROLL for (int l = 0; l < 9; ++l) {
+                    y[l] = fma(cm, xn[l] - xo[l], xn[l]);
+                    ry[l] = fma(cm, rn[l] - ro[l], rn[l]);
+                }
                 it_x += act ? 1 : 0;
-                act = adv;
+                act = act && !done;
+            };
+            for (int i = 0; i < maxit; i += 2) {
+                if (!__any(act)) break;
+                iterate(xa, ra, xb, rb, i);
+                if (i + 1 >= maxit || !__any(act)) break;
+                iterate(xb, rb, xa, ra, i + 1);
             }
-            if (kvalid) { UNROLL for (int l = 0; l < 9; ++l) Xg[l] = x[l]; }
+            double fin[9];
+            UNROLL for (int l = 0; l < 9; ++l) fin[l] = kvalid ? Xg[l] : 0.0;
 
             // dyn_violation = A_f X - b_f ; P += dyn_violation          (biconvex.cpp:98-99)
             double v2 = 0;
             {
                 double xn[9], w[9];
-                UNROLL for (int l = 0; l < 9; ++l) xn[l] = from_next(x[l]);
-                UNROLL for (int l = 0; l < 9; ++l) w[l] = x[l] - xn[l];
+                UNROLL for (int l = 0; l < 9; ++l) xn[l] = from_next(fin[l]);
+                UNROLL for (int l = 0; l < 9; ++l) w[l] = fin[l] - xn[l];
                 UNROLL for (int k = 0; k < 3; ++k) w[k] += dt * xn[3 + k];
-                w[6] += SY * x[2] - SZ * x[1];
-                w[7] += SZ * x[0] - SX * x[2];
-                w[8] += SX * x[1] - SY * x[0];
+                w[6] += SY * fin[2] - SZ * fin[1];
+                w[7] += SZ * fin[0] - SX * fin[2];
+                w[8] += SX * fin[1] - SY * fin[0];
                 UNROLL for (int l = 0; l < 9; ++l) {
                     const double d = rvalid ? (w[l] - bf[l]) : 0.0;
-                    const double di = l0 ? (x[l] - xin[l]) : 0.0;
-                    if (alive) { P[l] += d; PI[l] += di; }
+                    const double di = l0 ? (fin[l] - a.x_init[pb * 9 + l]) : 0.0;
+                    if (alive && rvalid) Pg[l] += d;
+                    if (alive && l0) PIg[l] += di;
                     v2 += d * d + di * di;
                 }
             }
@@ -433,10 +512,8 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
         }
     }
 
-    // ---- results
-    if (rvalid) { UNROLL for (int l = 0; l < 9; ++l) a.P[pb * nx + 9L * t + l] = P[l]; }
+    // ---- results (X, F, P are already in place)
     if (l0) {
-        UNROLL for (int l = 0; l < 9; ++l) a.P[pb * nx + 9L * H + l] = PI[l];
         a.L_x[pb] = L_x;
         a.L_f[pb] = L_f;
         if (a.dyn_viol) a.dyn_viol[pb] = last_viol;
@@ -458,12 +535,19 @@ __global__ __launch_bounds__(64) void lane_selftest_kernel(const double *in, dou
     out[320 + i] = (double)__popcll(__ballot(v > 0.0));
 }
 
-template <int LPP, bool RAW>
+template <int LPP, bool RAW, bool HASQF>
 hipError_t launch(const BatchArgs &a, hipStream_t stream) {
     const int per_wave = 64 / LPP;
     const unsigned grid = (unsigned)((a.B + per_wave - 1) / per_wave);
-    hipLaunchKernelGGL((biconvex_admm_kernel<LPP, 4, RAW>), dim3(grid), dim3(64), 0, stream, a);
+    const size_t lds = sizeof(double) * (size_t)(a.c.maxit > 0 ? a.c.maxit : 1);
+    hipLaunchKernelGGL((biconvex_admm_kernel<LPP, 4, RAW, HASQF>), dim3(grid), dim3(64), lds, stream, a);
     return hipGetLastError();
+}
+
+template <int LPP>
+hipError_t launch_lpp(const BatchArgs &a, hipStream_t stream) {
+    if (!a.raw) return launch<LPP, false, false>(a, stream);
+    return a.qf ? launch<LPP, true, true>(a, stream) : launch<LPP, true, false>(a, stream);
 }
 
 }  // namespace
@@ -471,10 +555,11 @@ hipError_t launch(const BatchArgs &a, hipStream_t stream) {
 hipError_t launch_biconvex_admm(const BatchArgs &a, int n_eff, hipStream_t stream) {
     if (n_eff != 4 || a.H < 1 || a.H + 1 > kMaxKnots || a.B < 0) return hipErrorInvalidValue;
     if (a.B == 0) return hipSuccess;
+    if (a.c.maxit > kMaxFistaIters) return hipErrorInvalidValue;
     const int k = a.H + 1;
-    if (k <= 16) return a.raw ? launch<16, true>(a, stream) : launch<16, false>(a, stream);
-    if (k <= 32) return a.raw ? launch<32, true>(a, stream) : launch<32, false>(a, stream);
-    return a.raw ? launch<64, true>(a, stream) : launch<64, false>(a, stream);
+    if (k <= 16) return launch_lpp<16>(a, stream);
+    if (k <= 32) return launch_lpp<32>(a, stream);
+    return launch_lpp<64>(a, stream);
 }
 
 hipError_t launch_lane_selftest(const double *in, double *out, hipStream_t stream) {

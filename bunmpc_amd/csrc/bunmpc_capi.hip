@@ -72,6 +72,7 @@ int check_batch(const bmpc_batch_t *d) {
     if (d->n_col + 1 > bunmpc::kMaxKnots)
         return fail(BMPC_BAD_ARG, "n_col + 1 > 64 knots is not supported by the one-knot-per-lane kernel");
     if (d->num_iters < 0 || d->maxit < 0) return fail(BMPC_BAD_ARG, "negative iteration cap");
+    if (d->maxit > bunmpc::kMaxFistaIters) return fail(BMPC_BAD_ARG, "maxit > 8192 is not supported");
     if (!d->cnt_plan || !d->dt || !d->x_init || !d->X || !d->F || !d->P || !d->L_x || !d->L_f)
         return fail(BMPC_BAD_ARG, "missing required array");
     if (d->raw) {
