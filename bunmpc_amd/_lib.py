@@ -92,7 +92,53 @@ _SIGS = {
     "bmpc_biconvex_solve_batch_device": (_I, [_P, _P]),
     "bmpc_biconvex_solve_batch_host": (_I, [_P]),
     "bmpc_biconvex_kernel_name": (C.c_char_p, [_I, _I]),
+    "bmpc_model_create": (_P, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "bmpc_model_destroy": (None, [_P]),
+    "bmpc_model_total_mass": (_D, [_P]),
+    "bmpc_ik_create": (_P, [_P, _I]),
+    "bmpc_ik_destroy": (None, [_P]),
+    "bmpc_ik_n_col": (_I, [_P]),
+    "bmpc_ik_setup_costs": (_I, [_P, _P, _I]),
+    "bmpc_ik_optimize": (_I, [_P, _P]),
+    "bmpc_ik_get_xs": (_I, [_P, _P]),
+    "bmpc_ik_get_us": (_I, [_P, _P]),
+    "bmpc_ik_return_opt_com": (_I, [_P, _P]),
+    "bmpc_ik_return_opt_mom": (_I, [_P, _P]),
+    "bmpc_ik_add_position_tracking_task": (_I, [_P, _I, _I, _I, _P, _D, C.c_char_p]),
+    "bmpc_ik_add_position_tracking_task_single": (_I, [_P, _I, _P, _D, C.c_char_p, _I]),
+    "bmpc_ik_add_terminal_position_tracking_task": (_I, [_P, _I, _P, _D, C.c_char_p]),
+    "bmpc_ik_add_velocity_tracking_task": (_I, [_P]),
+    "bmpc_ik_add_com_position_tracking_task": (_I, [_P, _I, _I, _P, _I, _D, C.c_char_p, _I]),
+    "bmpc_ik_add_centroidal_momentum_tracking_task": (_I, [_P, _I, _I, _P, _I, _D, C.c_char_p, _I]),
+    "bmpc_ik_add_state_regularization_cost": (_I, [_P, _I, _I, _D, C.c_char_p, _P, _P, _I]),
+    "bmpc_ik_add_state_regularization_cost_single": (_I, [_P, _I, _D, C.c_char_p, _P, _P]),
+    "bmpc_ik_add_ctrl_regularization_cost": (_I, [_P, _I, _I, _D, C.c_char_p, _P, _P, _I]),
+    "bmpc_ik_add_ctrl_regularization_cost_single": (_I, [_P, _I, _D, C.c_char_p, _P, _P]),
+    "bmpc_ik_last_stats": (_I, [_P, _P, _P, _P, _P]),
+    "bmpc_ik_workspace_doubles": (_I, [_I]),
+    "bmpc_ik_layout": (None, [_I, _P]),
+    "bmpc_ik_solve_batch_device": (_I, [_P, _P]),
+    "bmpc_ik_centroidal_state_device": (_I, [_P, _P, _P, _I, _P]),
+    "bmpc_kinodyn_create": (_P, [_P, _D, _I, _I, _I]),
+    "bmpc_kinodyn_destroy": (None, [_P]),
+    "bmpc_kinodyn_return_dyn": (_P, [_P]),
+    "bmpc_kinodyn_return_ik": (_P, [_P]),
+    "bmpc_kinodyn_optimize": (_I, [_P, _P, _P, _I, _I]),
+    "bmpc_kinodyn_set_com_tracking_weight": (_I, [_P, _D]),
+    "bmpc_kinodyn_set_mom_tracking_weight": (_I, [_P, _D]),
+    "bmpc_kinodyn_compute_solve_times": (_I, [_P]),
+    "bmpc_kinodyn_return_solve_times": (_I, [_P, _P]),
 }
+
+IK_NODE_TASK_DOUBLES = 33
+
+
+class IkBatch(C.Structure):
+    """bmpc_ik_batch_t"""
+    _fields_ = ([("B", C.c_int), ("n_col", C.c_int), ("maxiter", C.c_int), ("model", C.c_void_p)] +
+                [(n, C.c_void_p) for n in ("x0", "dt", "tasks", "state_w", "x_reg", "ctrl_w")] +
+                [("s_state_w", C.c_long), ("s_ctrl_w", C.c_long), ("ws", C.c_void_p), ("active", C.c_void_p),
+                 ("iters_run", C.c_void_p)])
 
 
 def exported_symbols():

@@ -193,3 +193,53 @@ class CentroidalDynamics:
 
     def __init__(self, m, n_col, n_eff):
         self.m, self.n_col, self.n_eff = float(m), int(n_col), int(n_eff)
+
+
+class KinoDynMP:
+    """motion_planner::KinoDynMP (srcpy/motion_planner/biconvex.cpp:55-63, src/motion_planner/kino_dyn.cpp).
+    `urdf` may be a URDF path (as in the reference), a RobotModel or a prepared DeviceModel."""
+
+    def __init__(self, urdf, m, n_eff, dyn_col, ik_col):
+        from .inverse_kinematics_cpp import InverseKinematics, as_device_model
+        self._lib = _lib.lib()
+        self._dm = as_device_model(urdf)
+        self._h = self._lib.bmpc_kinodyn_create(self._dm.h, float(m), int(n_eff), int(dyn_col), int(ik_col))
+        if not self._h:
+            raise _lib.BmpcError(_lib.BAD_ARG, _lib.last_error())
+        # return_dyn / return_ik hand out references to members (no keep_alive in the reference):
+        # here the wrappers hold a reference back to this object instead
+        self._dyn = BiconvexMP(m, dyn_col, n_eff, _handle=self._lib.bmpc_kinodyn_return_dyn(self._h), _owner=self)
+        self._ik = InverseKinematics(None, ik_col, _handle=self._lib.bmpc_kinodyn_return_ik(self._h), _owner=self,
+                                     _dmodel=self._dm)
+        self.nq, self.nv = self._dm.model.nq, self._dm.model.nv
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.bmpc_kinodyn_destroy(h)
+
+    def return_dyn(self):
+        return self._dyn
+
+    def return_ik(self):
+        return self._ik
+
+    def optimize(self, q, v, dyn_iters, kino_dyn_iters):
+        q, v = _vec(q, self.nq, "q"), _vec(v, self.nv, "v")
+        rc = self._lib.bmpc_kinodyn_optimize(self._h, q.ctypes.data, v.ctypes.data, int(dyn_iters), int(kino_dyn_iters))
+        if rc not in (_lib.OK, _lib.DIVERGED):
+            _lib.check(rc)
+
+    def set_com_tracking_weight(self, wt_com):     # the harness passes a 1-element ndarray (abstract_cyclic_gen.py:136-141)
+        _lib.check(self._lib.bmpc_kinodyn_set_com_tracking_weight(self._h, float(np.asarray(wt_com).reshape(-1)[0])))
+
+    def set_mom_tracking_weight(self, wt_mom):
+        _lib.check(self._lib.bmpc_kinodyn_set_mom_tracking_weight(self._h, float(np.asarray(wt_mom).reshape(-1)[0])))
+
+    def compute_solve_times(self):
+        _lib.check(self._lib.bmpc_kinodyn_compute_solve_times(self._h))
+
+    def return_solve_times(self):
+        out = np.zeros(3)
+        _lib.check(self._lib.bmpc_kinodyn_return_solve_times(self._h, out.ctypes.data))
+        return out

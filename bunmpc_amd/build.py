@@ -8,8 +8,8 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["biconvex_admm.hip", "bunmpc_capi.hip"]
-HEADERS = [os.path.join(CSRC, "biconvex_kernels.h"),
+SOURCES = ["biconvex_admm.hip", "bunmpc_capi.hip", "ik_ddp.hip", "bunmpc_ik_capi.hip"]
+HEADERS = [os.path.join(CSRC, "biconvex_kernels.h"), os.path.join(CSRC, "ik_types.h"), os.path.join(CSRC, "rbd_device.h"),
            os.path.join(os.path.dirname(_HERE), "include", "bunmpc.h")]
 LIB = os.path.join(_HERE, "libbunmpc_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

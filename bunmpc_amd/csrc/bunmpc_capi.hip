@@ -87,6 +87,10 @@ int check_batch(const bmpc_batch_t *d) {
 
 }  // namespace
 
+namespace bunmpc {
+int set_error(int code, const std::string &msg) { return fail(code, msg); }
+}  // namespace bunmpc
+
 // =============================================================== QuadrupedGait ==
 struct bmpc_gait {
     int n_eff;

@@ -1,0 +1,505 @@
+// C-ABI for the rigid-body model, InverseKinematics and KinoDynMP (include/bunmpc.h), host side.
+// Mirrors (behaviour, not code) ISL/include/ik/inverse_kinematics.hpp + ISL/src/ik/*.cpp and
+// ISL/src/motion_planner/kino_dyn.cpp; all numerics run in ik_ddp.hip / biconvex_admm.hip.
+#include "../../include/bunmpc.h"
+#include "ik_types.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+int ik_fail(int code, const std::string &msg) { return bunmpc::set_error(code, msg); }
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return ik_fail(BMPC_DEVICE_ERROR, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct Dev {
+    void *p = nullptr; size_t bytes = 0;
+    ~Dev() { if (p) (void)hipFree(p); }
+    hipError_t ensure(size_t n) {
+        if (n <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    double *d() const { return static_cast<double *>(p); }
+};
+
+}  // namespace
+
+struct bmpc_model {
+    bunmpc::RobotModelDev host;
+    Dev dev;            // device copy, uploaded lazily
+    bool uploaded = false;
+    int upload() {
+        if (uploaded) return BMPC_OK;
+        HIP_TRY(dev.ensure(sizeof(host)));
+        HIP_TRY(hipMemcpy(dev.p, &host, sizeof(host), hipMemcpyHostToDevice));
+        uploaded = true;
+        return BMPC_OK;
+    }
+    const bunmpc::RobotModelDev *dptr() const { return static_cast<const bunmpc::RobotModelDev *>(dev.p); }
+};
+
+// one residual cost of a node, as the reference's CostModelSum holds it (name -> item)
+struct IkItem { int kind; double wt; int frame; std::vector<double> ref; };  // kind: 0 frame 1 com 2 mom 3 state 4 ctrl
+
+struct bmpc_ik {
+    const bmpc_model *model;
+    int n_col;
+    std::vector<double> dt;
+    std::vector<std::map<std::string, IkItem>> nodes;   // n_col + 1 (last = terminal)
+    std::vector<double> state_w, x_reg, ctrl_w;
+    bool have_state = false, have_ctrl = false;
+    // results of the last optimize
+    std::vector<double> xs, us;
+    int iters = 0, status = 0;
+    double cost = 0, stop = 0;
+    bool solved = false;
+    Dev din, dws, dactive;
+};
+
+struct bmpc_kinodyn {
+    const bmpc_model *model;
+    double m; int n_eff, dyn_col, ik_col;
+    bmpc_biconvex_t *dyn; bmpc_ik *ik;
+    double wt_com = 0, wt_mom = 0;
+    bool profile = false;
+    double solve_times[3] = {0, 0, 0};
+    Dev dtmp;
+};
+
+namespace {
+
+int add_item(bmpc_ik *h, int t, const char *name, IkItem item) {
+    if (t < 0 || t > h->n_col) return ik_fail(BMPC_BAD_ARG, "time step out of range");
+    auto &m = h->nodes[t];
+    const std::string key = name ? name : "";
+    if (m.count(key)) {   // crocoddyl CostModelSum::addCost refuses duplicates with this message
+        std::cout << "Warning: we couldn't add the " << key << " cost item, it already existed." << std::endl;
+        return BMPC_OK;
+    }
+    m[key] = std::move(item);
+    return BMPC_OK;
+}
+
+// pack the accumulated costs into the kernel's per-node task blocks
+int pack_tasks(const bmpc_ik *h, std::vector<double> &tasks) {
+    using namespace bunmpc;
+    const int nn = h->n_col + 1;
+    tasks.assign((size_t)nn * kNodeTaskDoubles, 0.0);
+    for (int t = 0; t < nn; ++t) {
+        double *tk = tasks.data() + (size_t)t * kNodeTaskDoubles;
+        int slots = 0, ncom = 0, nmom = 0, nst = 0, nct = 0;
+        for (const auto &kv : h->nodes[t]) {
+            const IkItem &it = kv.second;
+            switch (it.kind) {
+            case 0:
+                if (slots == kFrameSlots) return ik_fail(BMPC_BAD_ARG, "more than 4 frame-translation costs on one node");
+                tk[5 * slots] = it.wt; tk[5 * slots + 1] = it.frame;
+                for (int c = 0; c < 3; ++c) tk[5 * slots + 2 + c] = it.ref[c];
+                ++slots; break;
+            case 1:
+                if (ncom++) return ik_fail(BMPC_BAD_ARG, "more than one CoM cost on one node");
+                tk[5 * kFrameSlots] = it.wt;
+                for (int c = 0; c < 3; ++c) tk[5 * kFrameSlots + 1 + c] = it.ref[c];
+                break;
+            case 2:
+                if (nmom++) return ik_fail(BMPC_BAD_ARG, "more than one momentum cost on one node");
+                tk[5 * kFrameSlots + 4] = it.wt;
+                for (int c = 0; c < 6; ++c) tk[5 * kFrameSlots + 5 + c] = it.ref[c];
+                break;
+            case 3:
+                if (nst++) return ik_fail(BMPC_BAD_ARG, "more than one state regularisation on one node");
+                tk[5 * kFrameSlots + 11] = it.wt; break;
+            case 4:
+                if (nct++) return ik_fail(BMPC_BAD_ARG, "more than one control regularisation on one node");
+                tk[5 * kFrameSlots + 12] = it.wt; break;
+            }
+        }
+    }
+    return BMPC_OK;
+}
+
+bunmpc::IkBatchArgs make_args(int B, int T, int maxiter, const bmpc_model *model, const double *x0, const double *dt,
+                              const double *tasks, const double *state_w, long s_sw, const double *x_reg,
+                              const double *ctrl_w, long s_cw, double *ws, int *active) {
+    bunmpc::IkBatchArgs a;
+    a.B = B; a.T = T; a.maxiter = maxiter; a.model = model->dptr();
+    a.x0 = x0; a.dt = dt; a.tasks = tasks; a.state_w = state_w; a.x_reg = x_reg; a.ctrl_w = ctrl_w;
+    a.s_state_w = s_sw; a.s_ctrl_w = s_cw; a.ws = ws; a.active = active;
+    return a;
+}
+
+// the DDP iteration loop (SolverDDP::solve): three launches per iteration, stop when every problem is done
+int run_ddp(const bunmpc::IkBatchArgs &a, hipStream_t st, int *iters_run) {
+    HIP_TRY(bunmpc::ik_launch_init(a, st));
+    int active = a.B, it = 0;
+    for (; it < a.maxiter && active > 0; ++it) {
+        HIP_TRY(bunmpc::ik_launch_calcdiff(a, st));
+        HIP_TRY(bunmpc::ik_launch_backward(a, st));
+        HIP_TRY(bunmpc::ik_launch_forward(a, st));
+        HIP_TRY(hipMemcpyAsync(&active, a.active, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (iters_run) *iters_run = it;
+    return BMPC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------------ model ----
+bmpc_model_t *bmpc_model_create(int nj, const int *parent, const double *R, const double *p, const double *axis,
+                                const double *mass, const double *com, const double *inertia, int nframes,
+                                const int *frame_body, const double *frame_p) {
+    using namespace bunmpc;
+    if (nj != kMaxJoints) { ik_fail(BMPC_BAD_ARG, "the kernels are built for 12 revolute joints after the free-flyer"); return nullptr; }
+    if (nframes < 0 || nframes > kMaxFrames) { ik_fail(BMPC_BAD_ARG, "too many frames"); return nullptr; }
+    auto *m = new bmpc_model;
+    RobotModelDev &h = m->host;
+    std::memset(&h, 0, sizeof(h));
+    h.nj = nj; h.nframes = nframes;
+    for (int i = 0; i < nj; ++i) {
+        h.parent[i] = parent[i];
+        if (parent[i] >= i || parent[i] < -1) { delete m; ik_fail(BMPC_BAD_ARG, "joints must be listed parents first"); return nullptr; }
+        std::memcpy(h.R[i], R + 9 * i, sizeof(double) * 9);
+        std::memcpy(h.p[i], p + 3 * i, sizeof(double) * 3);
+        std::memcpy(h.axis[i], axis + 3 * i, sizeof(double) * 3);
+    }
+    // serial chains only: every joint has at most one child, chain_end = last descendant
+    for (int i = 0; i < nj; ++i) {
+        int nchild = 0;
+        for (int j = 0; j < nj; ++j) nchild += parent[j] == i;
+        if (nchild > 1) { delete m; ik_fail(BMPC_BAD_ARG, "branching below the base is not supported"); return nullptr; }
+    }
+    for (int i = nj - 1; i >= 0; --i) {
+        h.chain_end[i] = i;
+        for (int j = i + 1; j < nj; ++j) if (parent[j] == i) h.chain_end[i] = h.chain_end[j];
+    }
+    for (int i = 0; i < nj; ++i)   // the subtree of joint i must be the contiguous index range i..chain_end[i]
+        for (int j = i + 1; j <= h.chain_end[i]; ++j)
+            if (parent[j] != j - 1) { delete m; ik_fail(BMPC_BAD_ARG, "chains must be numbered contiguously"); return nullptr; }
+    h.total_mass = 0;
+    for (int b = 0; b <= nj; ++b) {
+        h.mass[b] = mass[b]; h.total_mass += mass[b];
+        std::memcpy(h.com[b], com + 3 * b, sizeof(double) * 3);
+        const double *I = inertia + 9 * b;
+        h.inertia[b][0] = I[0]; h.inertia[b][1] = I[1]; h.inertia[b][2] = I[2];
+        h.inertia[b][3] = I[4]; h.inertia[b][4] = I[5]; h.inertia[b][5] = I[8];
+    }
+    for (int f = 0; f < nframes; ++f) {
+        if (frame_body[f] < 0 || frame_body[f] > nj) { delete m; ik_fail(BMPC_BAD_ARG, "frame body out of range"); return nullptr; }
+        h.frame_body[f] = frame_body[f];
+        std::memcpy(h.frame_p[f], frame_p + 3 * f, sizeof(double) * 3);
+    }
+    return m;
+}
+void bmpc_model_destroy(bmpc_model_t *m) { delete m; }
+double bmpc_model_total_mass(const bmpc_model_t *m) { return m ? m->host.total_mass : 0.0; }
+
+// ----------------------------------------------------------- InverseKinematics ----
+bmpc_ik_t *bmpc_ik_create(const bmpc_model_t *model, int n_col) {
+    if (!model || n_col < 1) { ik_fail(BMPC_BAD_ARG, "bad InverseKinematics arguments"); return nullptr; }
+    auto *h = new bmpc_ik;
+    h->model = model; h->n_col = n_col;
+    h->dt.assign(n_col, 0.0);
+    h->nodes.resize(n_col + 1);
+    return h;
+}
+void bmpc_ik_destroy(bmpc_ik_t *h) { delete h; }
+int bmpc_ik_n_col(const bmpc_ik_t *h) { return h ? h->n_col : 0; }
+
+int bmpc_ik_setup_costs(bmpc_ik_t *h, const double *dt, int n) {   // inverse_kinematics.cpp:37-52
+    if (!h || !dt) return ik_fail(BMPC_BAD_ARG, "null argument");
+    if (n < h->n_col) return ik_fail(BMPC_BAD_ARG, "dt must have n_col entries");
+    h->dt.assign(dt, dt + h->n_col);
+    return BMPC_OK;
+}
+
+#define IK_CHECK(...)                                                              \
+    if (!h) return ik_fail(BMPC_BAD_ARG, "null handle");                           \
+    { const void *ptrs_[] = {__VA_ARGS__};                                         \
+      for (const void *p_ : ptrs_) if (!p_) return ik_fail(BMPC_BAD_ARG, "null array argument"); }
+
+static int check_frame(const bmpc_ik *h, int frame) {
+    if (frame < 0 || frame >= h->model->host.nframes) return ik_fail(BMPC_BAD_ARG, "frame id out of range");
+    return BMPC_OK;
+}
+
+int bmpc_ik_add_position_tracking_task(bmpc_ik_t *h, int frame, int sn, int en, const double *traj3, double wt, const char *name) {
+    IK_CHECK(traj3);
+    if (int rc = check_frame(h, frame)) return rc;
+    for (int i = sn; i < en; ++i) {   // end_effector_tasks.cpp:8-19: name + std::to_string(i)
+        const std::string nm = std::string(name ? name : "") + std::to_string(i);
+        if (int rc = add_item(h, i, nm.c_str(), IkItem{0, wt, frame, {traj3[0], traj3[1], traj3[2]}})) return rc;
+    }
+    return BMPC_OK;
+}
+int bmpc_ik_add_position_tracking_task_single(bmpc_ik_t *h, int frame, const double *traj3, double wt, const char *name, int time_step) {
+    IK_CHECK(traj3);
+    if (int rc = check_frame(h, frame)) return rc;
+    if (time_step < 0 || time_step >= h->n_col) return ik_fail(BMPC_BAD_ARG, "time step out of range");
+    return add_item(h, time_step, name, IkItem{0, wt, frame, {traj3[0], traj3[1], traj3[2]}});
+}
+int bmpc_ik_add_terminal_position_tracking_task(bmpc_ik_t *h, int frame, const double *traj3, double wt, const char *name) {
+    IK_CHECK(traj3);
+    if (int rc = check_frame(h, frame)) return rc;
+    return add_item(h, h->n_col, name, IkItem{0, wt, frame, {traj3[0], traj3[1], traj3[2]}});
+}
+int bmpc_ik_add_velocity_tracking_task(bmpc_ik_t *h) {   // end_effector_tasks.cpp:49-56: a stub in the reference too
+    IK_CHECK(h);
+    std::cout << "function not implemented" << std::endl;
+    return BMPC_OK;
+}
+static int add_traj(bmpc_ik *h, int kind, int width, int sn, int en, const double *traj, int rows, double wt, const char *name, int is_terminal) {
+    if (!is_terminal) {
+        if (sn < 0 || en > h->n_col || rows < en - sn) return ik_fail(BMPC_BAD_ARG, "trajectory shorter than the node range");
+        for (int i = sn; i < en; ++i) {
+            std::vector<double> r(traj + (size_t)(i - sn) * width, traj + (size_t)(i - sn + 1) * width);
+            if (int rc = add_item(h, i, name, IkItem{kind, wt, -1, r})) return rc;
+        }
+        return BMPC_OK;
+    }
+    if (rows < 1) return ik_fail(BMPC_BAD_ARG, "empty trajectory");
+    return add_item(h, h->n_col, name, IkItem{kind, wt, -1, std::vector<double>(traj, traj + width)});
+}
+int bmpc_ik_add_com_position_tracking_task(bmpc_ik_t *h, int sn, int en, const double *traj, int rows, double wt, const char *name, int is_terminal) {
+    IK_CHECK(traj);
+    return add_traj(h, 1, 3, sn, en, traj, rows, wt, name, is_terminal);   // com_tasks.cpp:8-28
+}
+int bmpc_ik_add_centroidal_momentum_tracking_task(bmpc_ik_t *h, int sn, int en, const double *traj, int rows, double wt, const char *name, int is_terminal) {
+    IK_CHECK(traj);
+    return add_traj(h, 2, 6, sn, en, traj, rows, wt, name, is_terminal);   // com_tasks.cpp:30-50
+}
+static int set_state_vecs(bmpc_ik *h, const double *w, const double *xr) {
+    std::vector<double> nw(w, w + bunmpc::kNDX), nx(xr, xr + bunmpc::kNX);
+    if (h->have_state && (nw != h->state_w || nx != h->x_reg))
+        return ik_fail(BMPC_BAD_ARG, "differing stateWeights / x_reg between nodes are not supported");
+    h->state_w = nw; h->x_reg = nx; h->have_state = true;
+    return BMPC_OK;
+}
+static int set_ctrl_vec(bmpc_ik *h, const double *w) {
+    std::vector<double> nw(w, w + bunmpc::kNV);
+    if (h->have_ctrl && nw != h->ctrl_w) return ik_fail(BMPC_BAD_ARG, "differing controlWeights between nodes are not supported");
+    h->ctrl_w = nw; h->have_ctrl = true;
+    return BMPC_OK;
+}
+int bmpc_ik_add_state_regularization_cost(bmpc_ik_t *h, int sn, int en, double wt, const char *name, const double *w36, const double *xreg37, int is_terminal) {
+    IK_CHECK(w36, xreg37);   // regularization_costs.cpp:8-36
+    if (int rc = set_state_vecs(h, w36, xreg37)) return rc;
+    if (is_terminal) return add_item(h, h->n_col, name, IkItem{3, wt, -1, {}});
+    if (sn < 0 || en > h->n_col) return ik_fail(BMPC_BAD_ARG, "node range out of bounds");
+    for (int i = sn; i < en; ++i) if (int rc = add_item(h, i, name, IkItem{3, wt, -1, {}})) return rc;
+    return BMPC_OK;
+}
+int bmpc_ik_add_state_regularization_cost_single(bmpc_ik_t *h, int time_step, double wt, const char *name, const double *w36, const double *xreg37) {
+    IK_CHECK(w36, xreg37);
+    if (time_step < 0 || time_step >= h->n_col) return ik_fail(BMPC_BAD_ARG, "time step out of range");
+    if (int rc = set_state_vecs(h, w36, xreg37)) return rc;
+    return add_item(h, time_step, name, IkItem{3, wt, -1, {}});
+}
+int bmpc_ik_add_ctrl_regularization_cost(bmpc_ik_t *h, int sn, int en, double wt, const char *name, const double *w18, const double *ureg18, int is_terminal) {
+    IK_CHECK(w18);   // regularization_costs.cpp:66-93; u_reg is ignored there (ResidualModelControl(state_))
+    (void)ureg18;
+    if (int rc = set_ctrl_vec(h, w18)) return rc;
+    if (is_terminal) return add_item(h, h->n_col, name, IkItem{4, wt, -1, {}});
+    if (sn < 0 || en > h->n_col) return ik_fail(BMPC_BAD_ARG, "node range out of bounds");
+    for (int i = sn; i < en; ++i) if (int rc = add_item(h, i, name, IkItem{4, wt, -1, {}})) return rc;
+    return BMPC_OK;
+}
+int bmpc_ik_add_ctrl_regularization_cost_single(bmpc_ik_t *h, int time_step, double wt, const char *name, const double *w18, const double *ureg18) {
+    IK_CHECK(w18);
+    (void)ureg18;
+    if (time_step < 0 || time_step >= h->n_col) return ik_fail(BMPC_BAD_ARG, "time step out of range");
+    if (int rc = set_ctrl_vec(h, w18)) return rc;
+    return add_item(h, time_step, name, IkItem{4, wt, -1, {}});
+}
+
+int bmpc_ik_workspace_doubles(int n_col) { return (int)bunmpc::IkLayout::make(n_col).total; }
+
+// InverseKinematics::optimize (inverse_kinematics.cpp:54-71): ShootingProblem + SolverDDP::solve(), then fresh cost sums
+int bmpc_ik_optimize(bmpc_ik_t *h, const double *x0) {
+    using namespace bunmpc;
+    IK_CHECK(x0);
+    auto *model = const_cast<bmpc_model *>(h->model);
+    if (int rc = model->upload()) return rc;
+    const int T = h->n_col, nn = T + 1;
+    std::vector<double> tasks;
+    if (int rc = pack_tasks(h, tasks)) return rc;
+    const IkLayout L = IkLayout::make(T);
+    std::vector<double> sw = h->have_state ? h->state_w : std::vector<double>(kNDX, 0.0);
+    std::vector<double> xr = h->have_state ? h->x_reg : std::vector<double>(kNX, 0.0);
+    if (!h->have_state) xr[6] = 1.0;
+    std::vector<double> cw = h->have_ctrl ? h->ctrl_w : std::vector<double>(kNV, 0.0);
+    // staging: x0 | dt | tasks | state_w | x_reg | ctrl_w
+    std::vector<double> stage;
+    auto push = [&](const double *p, size_t n) { size_t o = stage.size(); stage.insert(stage.end(), p, p + n); return o; };
+    const size_t o_x0 = push(x0, kNX), o_dt = push(h->dt.data(), T), o_tk = push(tasks.data(), tasks.size()),
+                 o_sw = push(sw.data(), kNDX), o_xr = push(xr.data(), kNX), o_cw = push(cw.data(), kNV);
+    HIP_TRY(h->din.ensure(sizeof(double) * stage.size()));
+    HIP_TRY(h->dws.ensure(sizeof(double) * (size_t)L.total));
+    HIP_TRY(h->dactive.ensure(sizeof(int)));
+    HIP_TRY(hipMemcpy(h->din.p, stage.data(), sizeof(double) * stage.size(), hipMemcpyHostToDevice));
+    const double *d = h->din.d();
+    IkBatchArgs a = make_args(1, T, 100, model, d + o_x0, d + o_dt, d + o_tk, d + o_sw, 0, d + o_xr, d + o_cw, 0, h->dws.d(),
+                              static_cast<int *>(h->dactive.p));
+    if (int rc = run_ddp(a, nullptr, nullptr)) return rc;
+    h->xs.resize((size_t)nn * kNX); h->us.resize((size_t)T * kNV);
+    double scal[16];
+    HIP_TRY(hipMemcpy(h->xs.data(), h->dws.d() + L.xs, sizeof(double) * h->xs.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h->us.data(), h->dws.d() + L.us, sizeof(double) * h->us.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(scal, h->dws.d() + L.scal, sizeof(scal), hipMemcpyDeviceToHost));
+    h->iters = (int)scal[S_ITERS]; h->status = (int)scal[S_STATUS]; h->cost = scal[S_COST]; h->stop = scal[S_STOP];
+    h->solved = true;
+    for (auto &m : h->nodes) m.clear();   // rcost_arr_[i] / tcost_model_ replaced by empty CostModelSums
+    h->have_state = h->have_ctrl = false;
+    return BMPC_OK;
+}
+int bmpc_ik_get_xs(const bmpc_ik_t *h, double *xs) {
+    IK_CHECK(xs);
+    if (!h->solved) return ik_fail(BMPC_BAD_ARG, "optimize has not been called");
+    std::memcpy(xs, h->xs.data(), sizeof(double) * h->xs.size());
+    return BMPC_OK;
+}
+int bmpc_ik_get_us(const bmpc_ik_t *h, double *us) {
+    IK_CHECK(us);
+    if (!h->solved) return ik_fail(BMPC_BAD_ARG, "optimize has not been called");
+    std::memcpy(us, h->us.data(), sizeof(double) * h->us.size());
+    return BMPC_OK;
+}
+static int com_mom(bmpc_ik *h, double *com, double *mom) {
+    using namespace bunmpc;
+    if (!h->solved) return ik_fail(BMPC_BAD_ARG, "optimize has not been called");
+    const int nn = h->n_col + 1;
+    Dev out;
+    HIP_TRY(out.ensure(sizeof(double) * nn * 9));
+    const IkLayout L = IkLayout::make(h->n_col);
+    HIP_TRY(ik_launch_com_mom(h->model->dptr(), h->dws.d() + L.xs, out.d(), out.d() + nn * 3, nn, nullptr));
+    if (com) HIP_TRY(hipMemcpy(com, out.d(), sizeof(double) * nn * 3, hipMemcpyDeviceToHost));
+    if (mom) HIP_TRY(hipMemcpy(mom, out.d() + nn * 3, sizeof(double) * nn * 6, hipMemcpyDeviceToHost));
+    return BMPC_OK;
+}
+int bmpc_ik_return_opt_com(bmpc_ik_t *h, double *com) { IK_CHECK(com); return com_mom(h, com, nullptr); }   // :73-82
+int bmpc_ik_return_opt_mom(bmpc_ik_t *h, double *mom) { IK_CHECK(mom); return com_mom(h, nullptr, mom); }   // :84-93
+int bmpc_ik_last_stats(const bmpc_ik_t *h, int *iters, int *status, double *cost, double *stop) {
+    IK_CHECK(h);
+    if (iters) *iters = h->iters;
+    if (status) *status = h->status;
+    if (cost) *cost = h->cost;
+    if (stop) *stop = h->stop;
+    return BMPC_OK;
+}
+
+// batch: many independent IK problems, everything on the device
+int bmpc_ik_solve_batch_device(const bmpc_ik_batch_t *d, void *hip_stream) {
+    using namespace bunmpc;
+    if (!d || !d->model) return ik_fail(BMPC_BAD_ARG, "null batch descriptor / model");
+    if (d->B < 0 || d->n_col < 1 || d->maxiter < 1) return ik_fail(BMPC_BAD_ARG, "bad sizes");
+    if (!d->x0 || !d->dt || !d->tasks || !d->state_w || !d->x_reg || !d->ctrl_w || !d->ws || !d->active)
+        return ik_fail(BMPC_BAD_ARG, "missing array");
+    if (d->B == 0) return BMPC_OK;
+    auto *model = const_cast<bmpc_model *>(d->model);
+    if (int rc = model->upload()) return rc;
+    IkBatchArgs a = make_args(d->B, d->n_col, d->maxiter, model, d->x0, d->dt, d->tasks, d->state_w, d->s_state_w, d->x_reg,
+                              d->ctrl_w, d->s_ctrl_w, d->ws, d->active);
+    int iters = 0;
+    int rc = run_ddp(a, static_cast<hipStream_t>(hip_stream), &iters);
+    if (d->iters_run) *d->iters_run = iters;
+    return rc;
+}
+int bmpc_ik_centroidal_state_device(const bmpc_model_t *model, const double *x, double *out9, int B, void *hip_stream) {
+    if (!model || !x || !out9) return ik_fail(BMPC_BAD_ARG, "null argument");
+    auto *m = const_cast<bmpc_model *>(model);
+    if (int rc = m->upload()) return rc;
+    HIP_TRY(bunmpc::ik_launch_centroidal_state(m->dptr(), x, out9, B, static_cast<hipStream_t>(hip_stream)));
+    return BMPC_OK;
+}
+void bmpc_ik_layout(int n_col, long *offsets8) {   // xs, us, scal, K, kff, fs, Lx, Lxx offsets for callers that read the workspace
+    const bunmpc::IkLayout L = bunmpc::IkLayout::make(n_col);
+    offsets8[0] = L.xs; offsets8[1] = L.us; offsets8[2] = L.scal; offsets8[3] = L.K; offsets8[4] = L.kff;
+    offsets8[5] = L.fs; offsets8[6] = L.Lx; offsets8[7] = L.Lxx;
+}
+
+// ------------------------------------------------------------------- KinoDynMP ----
+bmpc_kinodyn_t *bmpc_kinodyn_create(const bmpc_model_t *model, double m, int n_eff, int dyn_col, int ik_col) {
+    if (!model || ik_col < 1 || ik_col > dyn_col) { ik_fail(BMPC_BAD_ARG, "bad KinoDynMP arguments"); return nullptr; }
+    auto *h = new bmpc_kinodyn;
+    h->model = model; h->m = m; h->n_eff = n_eff; h->dyn_col = dyn_col; h->ik_col = ik_col;
+    h->dyn = bmpc_biconvex_create(m, dyn_col, n_eff);
+    h->ik = bmpc_ik_create(model, ik_col);
+    if (!h->dyn || !h->ik) { bmpc_biconvex_destroy(h->dyn); bmpc_ik_destroy(h->ik); delete h; return nullptr; }
+    std::cout << "Initialized Kino-Dyn planner" << std::endl;   // kino_dyn.cpp:8
+    return h;
+}
+void bmpc_kinodyn_destroy(bmpc_kinodyn_t *h) { if (h) { bmpc_biconvex_destroy(h->dyn); bmpc_ik_destroy(h->ik); delete h; } }
+bmpc_biconvex_t *bmpc_kinodyn_return_dyn(bmpc_kinodyn_t *h) { return h ? h->dyn : nullptr; }
+bmpc_ik_t *bmpc_kinodyn_return_ik(bmpc_kinodyn_t *h) { return h ? h->ik : nullptr; }
+int bmpc_kinodyn_set_com_tracking_weight(bmpc_kinodyn_t *h, double w) { IK_CHECK(h); h->wt_com = w; return BMPC_OK; }
+int bmpc_kinodyn_set_mom_tracking_weight(bmpc_kinodyn_t *h, double w) { IK_CHECK(h); h->wt_mom = w; return BMPC_OK; }
+int bmpc_kinodyn_compute_solve_times(bmpc_kinodyn_t *h) { IK_CHECK(h); h->profile = true; return BMPC_OK; }
+int bmpc_kinodyn_return_solve_times(const bmpc_kinodyn_t *h, double *t3) { IK_CHECK(t3); std::memcpy(t3, h->solve_times, sizeof(h->solve_times)); return BMPC_OK; }
+
+// KinoDynMP::optimize (kino_dyn.cpp:39-81)
+int bmpc_kinodyn_optimize(bmpc_kinodyn_t *h, const double *q, const double *v, int dyn_iters, int kino_dyn_iters) {
+    using namespace bunmpc;
+    IK_CHECK(q, v);
+    (void)kino_dyn_iters;   // unused in the reference as well
+    const auto t1 = std::chrono::steady_clock::now();
+    auto *model = const_cast<bmpc_model *>(h->model);
+    if (int rc = model->upload()) return rc;
+    double x0[kNX];
+    std::memcpy(x0, q, sizeof(double) * kNQ);
+    std::memcpy(x0 + kNQ, v, sizeof(double) * kNV);
+    // computeCentroidalMomentum(q, v) -> [com, vcom, hg.angular]
+    HIP_TRY(h->dtmp.ensure(sizeof(double) * (kNX + 9)));
+    HIP_TRY(hipMemcpy(h->dtmp.p, x0, sizeof(x0), hipMemcpyHostToDevice));
+    HIP_TRY(ik_launch_centroidal_state(model->dptr(), h->dtmp.d(), h->dtmp.d() + kNX, 1, nullptr));
+    double c9[9];
+    HIP_TRY(hipMemcpy(c9, h->dtmp.d() + kNX, sizeof(c9), hipMemcpyDeviceToHost));
+    // set_warm_starts (kino_dyn.cpp:83-99): X = tile(c9), F = 0, P = 0
+    const int H = h->dyn_col, nx = 9 * (H + 1), nf = 3 * h->n_eff * H;
+    std::vector<double> X(nx), F(nf, 0.0), P(nx, 0.0);
+    for (int i = 0; i <= H; ++i) std::memcpy(X.data() + 9 * i, c9, sizeof(c9));
+    if (int rc = bmpc_biconvex_set_warm_start_vars(h->dyn, X.data(), F.data(), P.data())) return rc;
+    const auto t2 = std::chrono::steady_clock::now();
+    int rc_dyn = bmpc_biconvex_optimize(h->dyn, c9, dyn_iters);
+    if (rc_dyn != BMPC_OK && rc_dyn != BMPC_DIVERGED) return rc_dyn;
+    const auto t3 = std::chrono::steady_clock::now();
+    std::vector<double> com((size_t)(H + 1) * 3), mom((size_t)(H + 1) * 6);
+    bmpc_biconvex_return_opt_com(h->dyn, com.data());
+    bmpc_biconvex_return_opt_mom(h->dyn, mom.data());
+    const int T = h->ik_col;
+    // kino_dyn.cpp:53-56
+    if (int rc = bmpc_ik_add_centroidal_momentum_tracking_task(h->ik, 0, T, mom.data(), T, h->wt_mom, "mom_track", 0)) return rc;
+    if (int rc = bmpc_ik_add_centroidal_momentum_tracking_task(h->ik, 0, T, mom.data() + 6 * T, 1, h->wt_mom, "mom_track_ter", 1)) return rc;
+    if (int rc = bmpc_ik_add_com_position_tracking_task(h->ik, 0, T, com.data(), T, h->wt_com, "com_track", 0)) return rc;
+    if (int rc = bmpc_ik_add_com_position_tracking_task(h->ik, 0, T, com.data() + 3 * T, 1, h->wt_com, "com_track", 1)) return rc;
+    const auto t4 = std::chrono::steady_clock::now();
+    if (int rc = bmpc_ik_optimize(h->ik, x0)) return rc;
+    const auto t5 = std::chrono::steady_clock::now();
+    if (h->profile) {
+        h->solve_times[0] = std::chrono::duration<double>(t3 - t2).count();
+        h->solve_times[1] = std::chrono::duration<double>(t5 - t4).count();
+        h->solve_times[2] = std::chrono::duration<double>(t5 - t1).count();
+        std::cout << "Dyn optimize time : " << h->solve_times[0] << std::endl;
+        std::cout << "Kin optimize time : " << h->solve_times[1] << std::endl;
+        std::cout << "Total optimize time : " << h->solve_times[2] << std::endl;
+        std::cout << "===============================================" << std::endl;
+    }
+    return rc_dyn;
+}
+
+}  // extern "C"

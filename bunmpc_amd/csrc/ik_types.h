@@ -1,0 +1,84 @@
+// Internal types shared by the IK-DDP kernels (ik_ddp.hip) and the C-ABI host code.
+// Restates, for the GPU, what the reference obtains from pinocchio 2.6.9 / crocoddyl 1.9.0 through
+// ISL/src/ik/*.cpp (see oracle/rbd_np.py and oracle/ik_ddp_np.py for the CPU restatement).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+
+namespace bunmpc {
+
+// records the thread-local text bmpc_last_error() returns; returns `code` (bunmpc_capi.hip)
+int set_error(int code, const std::string &msg);
+
+constexpr int kMaxJoints = 12;   // revolute joints after the free-flyer (serial chains off the base)
+constexpr int kMaxFrames = 64;
+constexpr int kNV = 18, kNQ = 19, kNX = 37, kNDX = 36;   // the kernels are built for 12 joints
+constexpr int kFrameSlots = 4;   // frame-translation tasks per node (the harness adds <= n_eff)
+
+// Rigid-body model (device copy).  Body 0 = base, body i+1 = joint i.
+struct RobotModelDev {
+    int nj, nframes;
+    int parent[kMaxJoints];          // -1 = base, else joint index
+    int chain_end[kMaxJoints];       // last joint of the serial chain joint i belongs to
+    double R[kMaxJoints][9], p[kMaxJoints][3], axis[kMaxJoints][3];
+    double mass[kMaxJoints + 1], com[kMaxJoints + 1][3], inertia[kMaxJoints + 1][6];  // xx xy xz yy yz zz
+    int frame_body[kMaxFrames];
+    double frame_p[kMaxFrames][3];
+    double total_mass;
+};
+
+// Per-problem task description, one block per node t = 0..T (T = terminal):
+//   frame slots: weight, frame index (as double), ref(3)           -> 5 doubles x kFrameSlots
+//   com:  weight, ref(3)                                            -> 4
+//   mom:  weight, ref(6)                                            -> 7
+//   state reg weight, ctrl reg weight                               -> 2
+constexpr int kNodeTaskDoubles = 5 * kFrameSlots + 4 + 7 + 2;
+
+// Layout of the per-problem DDP workspace in HBM (doubles), T = number of running nodes.
+struct IkLayout {
+    int T;
+    long xs, us, xs_try, us_try, fs, xnext, Lx, Lxx, Lu, Luu, A6, B6, K, kff, Qu, Quuk, scal, total;
+    __host__ __device__ static IkLayout make(int T) {
+        IkLayout l; l.T = T;
+        long o = 0;
+        auto take = [&](long n) { long r = o; o += n; return r; };
+        l.xs = take((long)(T + 1) * kNX); l.us = take((long)T * kNV);
+        l.xs_try = take((long)(T + 1) * kNX); l.us_try = take((long)T * kNV);
+        l.fs = take((long)(T + 1) * kNDX); l.xnext = take((long)T * kNX);
+        l.Lx = take((long)(T + 1) * kNDX); l.Lxx = take((long)(T + 1) * kNDX * kNDX);
+        l.Lu = take((long)T * kNV); l.Luu = take((long)T * kNV);
+        l.A6 = take((long)T * 36); l.B6 = take((long)T * 36);
+        l.K = take((long)T * kNV * kNDX); l.kff = take((long)T * kNV);
+        l.Qu = take((long)T * kNV); l.Quuk = take((long)T * kNV);
+        l.scal = take(16);
+        l.total = o;
+        return l;
+    }
+};
+// scalars kept per problem in ws[scal + i]
+enum IkScal { S_COST = 0, S_XREG, S_D1, S_D2, S_STOP, S_FEAS, S_WASFEAS, S_DONE, S_ITERS, S_RECALC, S_STATUS, S_NODECOST };
+
+struct IkBatchArgs {
+    int B, T, maxiter;
+    const RobotModelDev *model;
+    const double *x0;          // [B][37]
+    const double *dt;          // [B][T]
+    const double *tasks;       // [B][T+1][kNodeTaskDoubles]
+    const double *state_w;     // [B or 1][36]   ActivationModelWeightedQuad weights of xReg
+    const double *x_reg;       // [B][37]
+    const double *ctrl_w;      // [B or 1][18]
+    long s_state_w, s_ctrl_w;  // batch strides (0 = shared)
+    double *ws;                // [B][layout.total]
+    int *active;               // device counter of problems still iterating
+};
+
+hipError_t ik_launch_init(const IkBatchArgs &a, hipStream_t s);
+hipError_t ik_launch_calcdiff(const IkBatchArgs &a, hipStream_t s);
+hipError_t ik_launch_backward(const IkBatchArgs &a, hipStream_t s);
+hipError_t ik_launch_forward(const IkBatchArgs &a, hipStream_t s);
+// centroidal state [com, vcom, L] (9) of (q, v): KinoDynMP::optimize's x0 (kino_dyn.cpp:42,86-97)
+hipError_t ik_launch_centroidal_state(const RobotModelDev *model, const double *x, double *out9, int B, hipStream_t s);
+// com (3) and h_g (6) along a state trajectory [B][n][37]  (InverseKinematics::return_opt_com/mom)
+hipError_t ik_launch_com_mom(const RobotModelDev *model, const double *xs, double *com, double *mom, int n_states, hipStream_t s);
+
+}  // namespace bunmpc

@@ -141,6 +141,90 @@ int bmpc_biconvex_solve_batch_host(const bmpc_batch_t *d);
 /* symbol-name prefix of the kernel that serves (n_col, raw), for profiles */
 const char *bmpc_biconvex_kernel_name(int n_col, int raw);
 
+/* rigid-body model -------------------------------------------------------------------
+ * What pinocchio::urdf::buildModel(urdf, JointModelFreeFlyer()) yields (inverse_kinematics.cpp:10,
+ * kino_dyn.cpp:9), as flat arrays (the Python shim parses the URDF: bunmpc_amd/urdf_model.py).
+ * nj must be 12 (free-flyer + serial chains numbered contiguously, parents first).
+ * R [nj][9], p [nj][3]: joint placement in the parent joint frame; axis [nj][3];
+ * bodies 0..nj (0 = base): mass, com [.][3], inertia about the com [.][9] (joint frame);
+ * frames: body index + position in that body's joint frame. */
+typedef struct bmpc_model bmpc_model_t;
+bmpc_model_t *bmpc_model_create(int nj, const int *parent, const double *R, const double *p, const double *axis,
+                                const double *mass, const double *com, const double *inertia, int nframes,
+                                const int *frame_body, const double *frame_p);
+void bmpc_model_destroy(bmpc_model_t *m);
+double bmpc_model_total_mass(const bmpc_model_t *m);
+
+/* inverse_kinematics_cpp.InverseKinematics -------------------------------------------
+ * srcpy/ik/inverse_kinematics.cpp:20-39 over src/ik/{inverse_kinematics,com_tasks,end_effector_tasks,
+ * regularization_costs}.cpp.  x = [q(19), v(18)], u = accelerations (18); frame = index into the
+ * model's frame list.  Costs accumulate per node until optimize() and are then discarded. */
+typedef struct bmpc_ik bmpc_ik_t;
+bmpc_ik_t *bmpc_ik_create(const bmpc_model_t *model, int n_col);                                   /* :21 */
+void bmpc_ik_destroy(bmpc_ik_t *h);
+int bmpc_ik_n_col(const bmpc_ik_t *h);
+int bmpc_ik_setup_costs(bmpc_ik_t *h, const double *dt, int n);                                     /* :22 */
+int bmpc_ik_optimize(bmpc_ik_t *h, const double *x0);                                               /* :23 */
+int bmpc_ik_get_xs(const bmpc_ik_t *h, double *xs);          /* (n_col+1) x 37                        :24 */
+int bmpc_ik_get_us(const bmpc_ik_t *h, double *us);          /* n_col x 18                            :25 */
+int bmpc_ik_return_opt_com(bmpc_ik_t *h, double *com);       /* (n_col+1) x 3                         :26 */
+int bmpc_ik_return_opt_mom(bmpc_ik_t *h, double *mom);       /* (n_col+1) x 6                         :27 */
+int bmpc_ik_add_position_tracking_task(bmpc_ik_t *h, int frame, int sn, int en, const double *traj3,
+                                       double wt, const char *name);                               /* :29 */
+int bmpc_ik_add_position_tracking_task_single(bmpc_ik_t *h, int frame, const double *traj3, double wt,
+                                              const char *name, int time_step);                    /* :30 */
+int bmpc_ik_add_terminal_position_tracking_task(bmpc_ik_t *h, int frame, const double *traj3, double wt,
+                                                const char *name);                                 /* :31 */
+int bmpc_ik_add_velocity_tracking_task(bmpc_ik_t *h);        /* prints "function not implemented"     :32 */
+int bmpc_ik_add_com_position_tracking_task(bmpc_ik_t *h, int sn, int en, const double *traj, int rows,
+                                           double wt, const char *name, int is_terminal);          /* :33 */
+int bmpc_ik_add_centroidal_momentum_tracking_task(bmpc_ik_t *h, int sn, int en, const double *traj, int rows,
+                                                  double wt, const char *name, int is_terminal);   /* :34 */
+int bmpc_ik_add_state_regularization_cost(bmpc_ik_t *h, int sn, int en, double wt, const char *name,
+                                          const double *w36, const double *xreg37, int is_terminal); /* :35 */
+int bmpc_ik_add_state_regularization_cost_single(bmpc_ik_t *h, int time_step, double wt, const char *name,
+                                                 const double *w36, const double *xreg37);        /* :36 */
+int bmpc_ik_add_ctrl_regularization_cost(bmpc_ik_t *h, int sn, int en, double wt, const char *name,
+                                         const double *w18, const double *ureg18, int is_terminal); /* :37 */
+int bmpc_ik_add_ctrl_regularization_cost_single(bmpc_ik_t *h, int time_step, double wt, const char *name,
+                                                const double *w18, const double *ureg18);         /* :38 */
+/* additive: DDP telemetry of the last optimize; status 0 converged, 1 maxiter, 2 regularisation maxed */
+int bmpc_ik_last_stats(const bmpc_ik_t *h, int *iters, int *status, double *cost, double *stop);
+
+/* batch of independent IK problems (additive).  Device pointers:
+ *   x0 [B][37], dt [B][n_col], tasks [B][n_col+1][BMPC_IK_NODE_TASK_DOUBLES] per node:
+ *       4 x {weight, frame, ref(3)} | com {weight, ref(3)} | mom {weight, ref(6)} | state weight | ctrl weight
+ *   state_w [.][36], ctrl_w [.][18] (batch stride 0 = shared), x_reg [B][37]
+ *   ws [B][bmpc_ik_workspace_doubles(n_col)] scratch + results (offsets: bmpc_ik_layout), active: one int */
+#define BMPC_IK_NODE_TASK_DOUBLES 33
+typedef struct {
+    int B, n_col, maxiter;
+    const bmpc_model_t *model;
+    const double *x0, *dt, *tasks, *state_w, *x_reg, *ctrl_w;
+    long s_state_w, s_ctrl_w;
+    double *ws;
+    int *active;
+    int *iters_run;   /* host int or NULL: DDP iterations the loop executed */
+} bmpc_ik_batch_t;
+int bmpc_ik_workspace_doubles(int n_col);
+void bmpc_ik_layout(int n_col, long *offsets8);   /* xs, us, scalars, K, k, fs, Lx, Lxx */
+int bmpc_ik_solve_batch_device(const bmpc_ik_batch_t *d, void *hip_stream);
+/* [com, vcom, hg.angular] of x = [q, v]: what KinoDynMP::optimize feeds the centroidal solve (kino_dyn.cpp:42,86-97) */
+int bmpc_ik_centroidal_state_device(const bmpc_model_t *model, const double *x, double *out9, int B, void *hip_stream);
+
+/* biconvex_mpc_cpp.KinoDynMP ---------------------------------------------------------
+ * srcpy/motion_planner/biconvex.cpp:55-63 over src/motion_planner/kino_dyn.cpp */
+typedef struct bmpc_kinodyn bmpc_kinodyn_t;
+bmpc_kinodyn_t *bmpc_kinodyn_create(const bmpc_model_t *model, double m, int n_eff, int dyn_col, int ik_col); /* :56 */
+void bmpc_kinodyn_destroy(bmpc_kinodyn_t *h);
+bmpc_biconvex_t *bmpc_kinodyn_return_dyn(bmpc_kinodyn_t *h);      /* borrowed, owned by h           :57 */
+bmpc_ik_t *bmpc_kinodyn_return_ik(bmpc_kinodyn_t *h);             /* borrowed, owned by h           :58 */
+int bmpc_kinodyn_optimize(bmpc_kinodyn_t *h, const double *q, const double *v, int dyn_iters, int kino_dyn_iters); /* :59 */
+int bmpc_kinodyn_set_com_tracking_weight(bmpc_kinodyn_t *h, double w);                              /* :60 */
+int bmpc_kinodyn_set_mom_tracking_weight(bmpc_kinodyn_t *h, double w);                              /* :61 */
+int bmpc_kinodyn_compute_solve_times(bmpc_kinodyn_t *h);                                            /* :62 */
+int bmpc_kinodyn_return_solve_times(const bmpc_kinodyn_t *h, double *t3);  /* dyn, ik, total seconds  :63 */
+
 #ifdef __cplusplus
 }
 #endif

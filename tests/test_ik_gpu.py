@@ -1,0 +1,135 @@
+"""GPU tests of the whole-body IK-DDP (ik_ddp.hip) through the C-ABI classes against the numpy
+restatement of crocoddyl 1.9.0's SolverDDP on the reference's cost set (oracle/ik_ddp_np.py).
+PARITY UNPINNED: crocoddyl / pinocchio are absent; the oracle itself is pinned by finite differences."""
+import os
+
+import numpy as np
+import pytest
+
+from bunmpc_amd import problems, urdf_model
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+ROBOT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bunmpc_amd", "robots", "solo12.json")
+FEET = ["FL_FOOT", "FR_FOOT", "HL_FOOT", "HR_FOOT"]
+Q0 = np.array([0, 0, 0.25, 0, 0, 0, 1] + [0, 0.8, -1.6] * 2 + [0, -0.8, 1.6] * 2, float)
+STATE_WT = np.array([0., 0, 10] + [1000] * 3 + [1.0] * 12 + [0.] * 3 + [100] * 3 + [0.5] * 12)   # solo12_trot.py:22-23
+CTRL_WT = np.array([0, 0, 1000] + [5e2] * 3 + [1.0] * 12)                                           # solo12_trot.py:25
+
+
+def build_costs(ik, b, T, com_opt, mom_opt, q_reg, wt_com=0.0, wt_mom=5e2):
+    """create_costs (abstract_cyclic_gen.py:545-562) + KinoDynMP::optimize's tracking tasks (kino_dyn.cpp:53-56)"""
+    for i in range(T):
+        for j, f in enumerate(FEET):
+            if b.cnt_plan[0, i, j, 0] == 1:
+                ik.add_position_tracking_task_single(f, b.cnt_plan[0, i, j, 1:4], 1e4, "cnt_0" + f, i)
+            elif b.swing_time[0, i, j] == 1:
+                pos = b.cnt_plan[0, i, j, 1:4].copy()
+                pos[2] = problems.TROT.step_ht
+                ik.add_position_tracking_task_single(f, pos, 1e4, "via_0" + f, i)
+    x_reg = np.concatenate([q_reg, np.zeros(18)])
+    ik.add_state_regularization_cost(0, T, 5e-2, "xReg", STATE_WT, x_reg, False)
+    ik.add_ctrl_regularization_cost(0, T, 1e-5, "uReg", CTRL_WT, np.zeros(18), False)
+    ik.add_state_regularization_cost(0, T, 5e-2, "xReg", STATE_WT, x_reg, True)
+    ik.add_ctrl_regularization_cost(0, T, 1e-5, "uReg", CTRL_WT, np.zeros(18), True)
+    ik.setup_costs(b.dt[0, :T])
+    ik.add_centroidal_momentum_tracking_task(0, T, mom_opt[:T], wt_mom, "mom_track", False)
+    ik.add_centroidal_momentum_tracking_task(0, T, mom_opt[T:T + 1], wt_mom, "mom_track_ter", True)
+    ik.add_com_position_tracking_task(0, T, com_opt[:T], wt_com, "com_track", False)
+    ik.add_com_position_tracking_task(0, T, com_opt[T:T + 1], wt_com, "com_track", True)
+
+
+@pytest.fixture(scope="module")
+def model():
+    return urdf_model.RobotModel.from_json(open(ROBOT).read())
+
+
+def test_ik_matches_numpy_ddp(model, oracle):
+    from bunmpc_amd.inverse_kinematics_cpp import InverseKinematics
+    from oracle import ik_ddp_np
+    b = problems.make_batch("solo12_trot_nominal", 1)
+    r = oracle.solve_batch(b, num_iters=10)
+    X = r["X"][0].reshape(-1, 9)
+    com_opt, mom_opt = X[:, 0:3], np.hstack([b.m * X[:, 3:6], X[:, 6:9]])
+    T = 10
+    x0 = np.concatenate([Q0, 0.05 * np.random.default_rng(0).standard_normal(18)])
+    ref_prob = ik_ddp_np.IKProblem(model, T)
+    build_costs(ref_prob, b, T, com_opt, mom_opt, Q0)
+    ref = ik_ddp_np.solve_ddp(ref_prob, x0)
+    ik = InverseKinematics(model, T)
+    build_costs(ik, b, T, com_opt, mom_opt, Q0)
+    ik.optimize(x0)
+    st = ik.last_stats()
+    print("gpu", st, "oracle iters", ref["iters"], ref["cost"], ref["stop"])
+    assert st["status"] == 0 and ref["converged"]
+    assert st["iters"] == ref["iters"]
+    assert abs(st["cost"] - ref["cost"]) <= 1e-9 * abs(ref["cost"])
+    xs, us = np.array(ik.get_xs()), np.array(ik.get_us())
+    assert rel_l2(xs.reshape(-1), np.array(ref["xs"]).reshape(-1)) < 1e-8
+    assert rel_l2(us.reshape(-1), np.array(ref["us"]).reshape(-1)) < 1e-6
+    # return_opt_com / return_opt_mom against the oracle's kinematics of the same states
+    from oracle import rbd_np as rb
+    k = [rb.Kin(model, x[:19], x[19:]) for x in xs]
+    assert np.allclose(ik.return_opt_com(), [kk.com for kk in k], atol=1e-12)
+    assert np.allclose(ik.return_opt_mom(), [kk.centroidal_momentum() for kk in k], atol=1e-12)
+
+
+def test_kinodyn_end_to_end(model, oracle):
+    """KinoDynMP.optimize(q, v, 10, 1): centroidal ADMM from (q, v), tracking tasks, IK-DDP."""
+    from bunmpc_amd.biconvex_mpc_cpp import KinoDynMP
+    from oracle import ik_ddp_np, rbd_np as rb
+    b = problems.make_batch("solo12_trot_nominal", 1)
+    H, T = b.H, 10
+    kd = KinoDynMP(model, model.total_mass, 4, H, T)
+    kd.set_com_tracking_weight(np.array([0.0]))
+    kd.set_mom_tracking_weight(np.array([5e2]))
+    mp, ik = kd.return_dyn(), kd.return_ik()
+    mp.set_rho(b.rho)
+    v0 = np.zeros(18)
+    kin = rb.Kin(model, Q0, v0)
+    x_init = np.concatenate([kin.com, kin.vcom(), kin.centroidal_momentum()[3:]])
+    for t in range(H):
+        mp.set_contact_plan(b.cnt_plan[0, t], b.dt[0, t])
+    mp.create_bound_constraints(b.bounds[0], 15.0, 15.0, 15.0)
+    mp.create_cost_X(b.W_X[0], b.W_X_ter[0], b.X_ter[0], b.X_nom[0])
+    mp.create_cost_F(b.W_F[0])
+    # IK costs that the harness adds before kd.optimize (tracking tasks are added inside it)
+    for i in range(T):
+        for j, f in enumerate(FEET):
+            if b.cnt_plan[0, i, j, 0] == 1:
+                ik.add_position_tracking_task_single(f, b.cnt_plan[0, i, j, 1:4], 1e4, "cnt_0" + f, i)
+    x_reg = np.concatenate([Q0, np.zeros(18)])
+    ik.add_state_regularization_cost(0, T, 5e-2, "xReg", STATE_WT, x_reg, False)
+    ik.add_ctrl_regularization_cost(0, T, 1e-5, "uReg", CTRL_WT, np.zeros(18), False)
+    ik.add_state_regularization_cost(0, T, 5e-2, "xReg", STATE_WT, x_reg, True)
+    ik.add_ctrl_regularization_cost(0, T, 1e-5, "uReg", CTRL_WT, np.zeros(18), True)
+    ik.setup_costs(b.dt[0, :T])
+    kd.compute_solve_times()
+    kd.optimize(Q0, v0, 10, 1)
+    # centroidal part equals the strict oracle started from the FK-derived x_init
+    b.x_init[0] = x_init
+    ref = oracle.solve_batch(b, num_iters=10)
+    assert rel_l2(mp.return_opt_x(), ref["X"][0]) < 1e-5 and rel_l2(mp.return_opt_f(), ref["F"][0]) < 1e-5
+    # IK part equals the numpy DDP on the same task set
+    X = mp.return_opt_x().reshape(-1, 9)
+    prob = ik_ddp_np.IKProblem(model, T)
+    for i in range(T):
+        for j, f in enumerate(FEET):
+            if b.cnt_plan[0, i, j, 0] == 1:
+                prob.add_position_tracking_task_single(f, b.cnt_plan[0, i, j, 1:4], 1e4, "cnt_0" + f, i)
+    prob.add_state_regularization_cost(0, T, 5e-2, "xReg", STATE_WT, x_reg, False)
+    prob.add_ctrl_regularization_cost(0, T, 1e-5, "uReg", CTRL_WT, np.zeros(18), False)
+    prob.add_state_regularization_cost(0, T, 5e-2, "xReg", STATE_WT, x_reg, True)
+    prob.add_ctrl_regularization_cost(0, T, 1e-5, "uReg", CTRL_WT, np.zeros(18), True)
+    prob.setup_costs(b.dt[0, :T])
+    mom = np.hstack([model.total_mass * X[:, 3:6], X[:, 6:9]])
+    prob.add_centroidal_momentum_tracking_task(0, T, mom[:T], 5e2, "mom_track", False)
+    prob.add_centroidal_momentum_tracking_task(0, T, mom[T:T + 1], 5e2, "mom_track_ter", True)
+    prob.add_com_position_tracking_task(0, T, X[:T, 0:3], 0.0, "com_track", False)
+    prob.add_com_position_tracking_task(0, T, X[T:T + 1, 0:3], 0.0, "com_track", True)
+    r = ik_ddp_np.solve_ddp(prob, np.concatenate([Q0, v0]))
+    xs = np.array(ik.get_xs())
+    assert ik.last_stats()["iters"] == r["iters"]
+    assert rel_l2(xs.reshape(-1), np.array(r["xs"]).reshape(-1)) < 1e-8
+    t = kd.return_solve_times()
+    assert t.shape == (3,) and t[2] >= t[0] + t[1] > 0
