@@ -128,6 +128,7 @@ _SIGS = {
     "bmpc_kinodyn_set_mom_tracking_weight": (_I, [_P, _D]),
     "bmpc_kinodyn_compute_solve_times": (_I, [_P]),
     "bmpc_kinodyn_return_solve_times": (_I, [_P, _P]),
+    "bmpc_kinodyn_solve_batch_device": (_I, [_P, _P]),
 }
 
 IK_NODE_TASK_DOUBLES = 33
@@ -139,6 +140,11 @@ class IkBatch(C.Structure):
                 [(n, C.c_void_p) for n in ("x0", "dt", "tasks", "state_w", "x_reg", "ctrl_w")] +
                 [("s_state_w", C.c_long), ("s_ctrl_w", C.c_long), ("ws", C.c_void_p), ("active", C.c_void_p),
                  ("iters_run", C.c_void_p)])
+
+
+class KinoDynBatch(C.Structure):
+    """bmpc_kinodyn_batch_t"""
+    _fields_ = [("dyn", Batch), ("ik", IkBatch), ("x", C.c_void_p)]
 
 
 def exported_symbols():

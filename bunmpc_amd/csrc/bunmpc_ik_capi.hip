@@ -433,6 +433,22 @@ void bmpc_ik_layout(int n_col, long *offsets8) {   // xs, us, scal, K, kff, fs, 
     offsets8[5] = L.fs; offsets8[6] = L.Lx; offsets8[7] = L.Lxx;
 }
 
+// batch of KinoDynMP::optimize calls, device resident: centroidal state of (q, v) -> ADMM (cold start)
+// -> tracking references -> IK-DDP
+int bmpc_kinodyn_solve_batch_device(const bmpc_kinodyn_batch_t *d, void *hip_stream) {
+    if (!d || !d->x || !d->ik.model) return ik_fail(BMPC_BAD_ARG, "null KinoDyn batch descriptor");
+    if (d->dyn.B != d->ik.B || d->ik.n_col > d->dyn.n_col) return ik_fail(BMPC_BAD_ARG, "inconsistent batch sizes / horizons");
+    if (d->dyn.B == 0) return BMPC_OK;
+    auto *model = const_cast<bmpc_model *>(d->ik.model);
+    if (int rc = model->upload()) return rc;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    HIP_TRY(bunmpc::ik_launch_centroidal_state(model->dptr(), d->x, const_cast<double *>(d->dyn.x_init), d->dyn.B, st));
+    if (int rc = bmpc_biconvex_solve_batch_device(&d->dyn, hip_stream)) return rc;
+    HIP_TRY(bunmpc::ik_launch_fill_refs(const_cast<double *>(d->ik.tasks), d->dyn.X, d->dyn.m, d->dyn.B, d->dyn.n_col,
+                                        d->ik.n_col, st));
+    return bmpc_ik_solve_batch_device(&d->ik, hip_stream);
+}
+
 // ------------------------------------------------------------------- KinoDynMP ----
 bmpc_kinodyn_t *bmpc_kinodyn_create(const bmpc_model_t *model, double m, int n_eff, int dyn_col, int ik_col) {
     if (!model || ik_col < 1 || ik_col > dyn_col) { ik_fail(BMPC_BAD_ARG, "bad KinoDynMP arguments"); return nullptr; }

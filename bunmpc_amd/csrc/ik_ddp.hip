@@ -585,7 +585,29 @@ __global__ void ik_com_mom_kernel(const RobotModelDev *model, const double *xs, 
     for (int c = 0; c < 6; ++c) mom[i * 6 + c] = k.hg[c];
 }
 
+// com / momentum references of the IK tracking tasks from the centroidal solution X
+// (KinoDynMP::optimize, kino_dyn.cpp:50-56: rows 0..T-1 running, row T terminal; mom = [m v, L])
+__global__ void kd_fill_refs_kernel(double *tasks, const double *X, double m, int B, int H, int T) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (long)B * (T + 1)) return;
+    const long b = id / (T + 1);
+    const int t = (int)(id % (T + 1));
+    double *tk = tasks + id * kNodeTaskDoubles;
+    const double *Xk = X + b * 9L * (H + 1) + 9L * t;
+    for (int c = 0; c < 3; ++c) {
+        tk[5 * kFrameSlots + 1 + c] = Xk[c];
+        tk[5 * kFrameSlots + 5 + c] = m * Xk[3 + c];
+        tk[5 * kFrameSlots + 8 + c] = Xk[6 + c];
+    }
+}
+
 }  // namespace
+
+hipError_t ik_launch_fill_refs(double *tasks, const double *X, double m, int B, int H, int T, hipStream_t st) {
+    const long n = (long)B * (T + 1);
+    hipLaunchKernelGGL(kd_fill_refs_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, tasks, X, m, B, H, T);
+    return hipGetLastError();
+}
 
 hipError_t ik_launch_init(const IkBatchArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(ik_init_kernel, dim3((a.B + 63) / 64), dim3(64), 0, st, a);

@@ -110,7 +110,7 @@ def gait_percent_in_phase(t, period, stance_percent, offset):
 
 
 # ------------------------------------------------------------- contact plan ---
-def contact_plan(gait, robot, H, t0, com_xy, z_height, feet0, v_des, w_des):
+def contact_plan(gait, robot, H, t0, com_xy, z_height, feet0, v_des, w_des, hip_offsets=None):
     """create_cnt_plan (abstract_cyclic_gen.py:159-414), data path (no MCTS / height map /
     noise), vectorised over the batch.
       t0 (B,), com_xy (B,2) already rounded, z_height (B,), feet0 (B,4,3) already rounded,
@@ -135,7 +135,8 @@ def contact_plan(gait, robot, H, t0, com_xy, z_height, feet0, v_des, w_des):
                 continue
             ft = np.round(t0 + i * gdt, 3)
             ph = gait_phase(ft, gait.gait_period, sp, off)
-            hip_loc = com_xy + robot.offsets_xy[j][None, :] + i * gdt * vtrack
+            hoff = robot.offsets_xy[j][None, :] if hip_offsets is None else hip_offsets[:, j]   # (R_yaw offsets[j])[0:2]
+            hip_loc = com_xy + hoff + i * gdt * vtrack
             raibert = 0.5 * vtrack * gait.gait_period * sp - 0.05 * (vtrack - v_des[:, 0:2])
             per_ph = np.round(gait_percent_in_phase(ft, gait.gait_period, sp, off), 3)
             prev_on = cnt[:, i - 1, j, 0] == 1
@@ -315,3 +316,107 @@ def make_batch(config, B, first=0, seed=None, H=None):
     return Batch(config, B, H, E, robot.mass, gaits[0].rho, cnt, dt, x_init, X_nom, X_ter,
                  W_X, W_X_ter, W_F, bounds, swing, gid, 10.0 if config == "go2_bound" else 1.0,
                  dict(seed=seed, first=first, t0=t0, v_des=v_des, gaits=[g.name for g in gaits]))
+
+
+# ------------------------------------------------------------------- whole-body batches ---
+SOLO12_Q0 = np.array([0, 0, 0.2409, 0, 0, 0, 1] + [0, 0.8, -1.6] * 2 + [0, -0.8, 1.6] * 2, float)  # feet at z = foot_size
+FEET = ("FL_FOOT", "FR_FOOT", "HL_FOOT", "HR_FOOT")     # abstract_cyclic_gen.py:37
+HIPS = ("FL_HFE", "FR_HFE", "HL_HFE", "HR_HFE")         # abstract_cyclic_gen.py:38
+# IK weights of the trot plan (motions/cyclic/solo12_trot.py:22-31)
+TROT_IK = dict(state_wt=np.array([0., 0, 10] + [1000] * 3 + [1.0] * 12 + [0.] * 3 + [100] * 3 + [0.5] * 12),
+               ctrl_wt=np.array([0, 0, 1000] + [5e2] * 3 + [1.0] * 12), swing_wt=(1e4, 1e4), cent_wt=(0.0, 5e2),
+               reg_wt=(5e-2, 1e-5))
+
+
+@dataclass
+class WholeBodyBatch:
+    """Inputs of B independent KinoDynMP.optimize(q, v, N, 1) calls as the harness prepares them."""
+    dyn: Batch                 # centroidal part (x_init = [com, vcom, L] of (q, v))
+    x: np.ndarray              # (B,37) [q, v]
+    ik_T: int
+    ik_tasks: np.ndarray       # (B, T+1, 33) kernel task blocks; com/mom refs are filled after the ADMM
+    state_w: np.ndarray        # (1,36)
+    ctrl_w: np.ndarray         # (1,18)
+    x_reg: np.ndarray          # (B,37)
+    wt_com: float
+    wt_mom: float
+    frame_ids: tuple
+
+
+def _log3_batch(R):
+    v = np.stack([R[:, 2, 1] - R[:, 1, 2], R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] - R[:, 0, 1]], axis=1)
+    t = np.arctan2(0.5 * np.linalg.norm(v, axis=1), 0.5 * (np.trace(R, axis1=1, axis2=2) - 1.0))
+    f = np.where(t < 1e-3, 0.5 * (1 + t * t / 6), t / (2 * np.sin(np.where(t < 1e-3, 1.0, t))))
+    return f[:, None] * v
+
+
+def make_wb_batch(model, B, first=0, seed=None, gait=TROT, ik=TROT_IK, ik_hor_ratio=0.5):
+    """Perturbed whole-body states and everything SoloMpcGaitGen.optimize hands to KinoDynMP
+    (abstract_cyclic_gen.py:629-663): contact plan from the feet / CoM of (q, v), centroidal costs
+    (create_costs :564-614) and the IK task list (:545-562).  Solo12 trot by default."""
+    from . import fk_np
+    seed = BASE_SEED + 5 if seed is None else seed
+    H = gait.horizon
+    T = int(np.round(ik_hor_ratio * gait.gait_horizon * gait.gait_period / gait.gait_dt, 2))   # :128
+    E = 4
+    u, nrm = _draws(seed, first, B, 48)
+    # state perturbation in the tangent space of q0
+    dq = np.zeros((B, 18))
+    dq[:, 2] = 0.01 * nrm[:, 0]
+    dq[:, 3:6] = 0.05 * nrm[:, 1:4]
+    dq[:, 6:] = 0.05 * nrm[:, 4:16]
+    q = np.tile(SOLO12_Q0, (B, 1))
+    q[:, 2] += dq[:, 2]
+    # small rotation: quaternion of exp(w)
+    w = dq[:, 3:6]
+    th = np.linalg.norm(w, axis=1)
+    sfac = np.where(th < 1e-8, 0.5, np.sin(0.5 * th) / np.where(th < 1e-8, 1.0, th))
+    q[:, 3:6] = sfac[:, None] * w
+    q[:, 6] = np.cos(0.5 * th)
+    q[:, 7:] += dq[:, 6:]
+    v = np.concatenate([0.1 * nrm[:, 16:19], 0.2 * nrm[:, 19:22], 0.2 * nrm[:, 22:34]], axis=1)
+    t0 = np.round(0.05 * np.floor(u[:, 0] * 10), 3)
+    v_des_b = np.zeros((B, 3))
+    v_des_b[:, 0] = 0.3 * u[:, 1]
+    kin = fk_np.kinematics(model, q, v)
+    Rb = kin["oR"][0]
+    v_des = np.einsum("bij,bj->bi", Rb, v_des_b)                    # :642-643
+    # constructor offsets from the nominal configuration (:41-76)
+    k0 = fk_np.kinematics(model, SOLO12_Q0[None])
+    offs = np.round(fk_np.frame_positions(model, k0, HIPS)[0] - k0["com"][0], 3)
+    offs[:, 1] += np.array([0.04, -0.04, 0.04, -0.04])
+    yaw = np.arctan2(Rb[:, 1, 0], Rb[:, 0, 0])
+    cy, sy = np.cos(yaw), np.sin(yaw)
+    hip_off = np.stack([cy[:, None] * offs[None, :, 0] - sy[:, None] * offs[None, :, 1],
+                        sy[:, None] * offs[None, :, 0] + cy[:, None] * offs[None, :, 1]], axis=2)   # (B,4,2)
+    feet0 = np.round(fk_np.frame_positions(model, kin, FEET), 3)
+    com_xy = np.round(kin["com"][:, 0:2], 3)
+    robot = RobotParams("solo12", model.total_mass, SOLO12.feet_xy, offs[:, 0:2], float(k0["com"][0, 2]))
+    cnt, swing, dt = contact_plan(gait, robot, H, t0, com_xy, kin["com"][:, 2], feet0, v_des, np.zeros(B), hip_off)
+    x_init = np.concatenate([kin["com"], kin["vcom"], kin["L"]], axis=1)
+    amom = _log3_batch(np.transpose(Rb, (0, 2, 1)))                   # log3(R_des R_q^T), R_des = I  (:616-627)
+    X_nom, X_ter = centroidal_costs(gait, H, x_init, v_des, dt, amom)
+    dyn = Batch("solo12_trot_wb", B, H, E, model.total_mass, gait.rho, cnt, dt, x_init, X_nom, X_ter,
+                np.tile(gait.W_X, H)[None], gait.W_X_ter[None].copy(), np.tile(gait.W_F, H)[None],
+                np.tile(BOUNDS_TILE, (H, 1))[None], swing, np.zeros(B, dtype=np.int64), 1.0,
+                dict(seed=seed, first=first, t0=t0, v_des=v_des))
+    # IK task blocks: 4 x {w, frame, ref3} | com {w, ref3} | mom {w, ref6} | state w | ctrl w
+    fid = tuple(model.frame_id(n) for n in FEET)
+    tasks = np.zeros((B, T + 1, 33))
+    for i in range(T):
+        for j in range(E):
+            on = cnt[:, i, j, 0] == 1
+            via = (~on) & (swing[:, i, j] == 1)
+            ref = cnt[:, i, j, 1:4].copy()
+            ref[via, 2] = gait.step_ht
+            tasks[:, i, 5 * j] = np.where(on, ik["swing_wt"][0], np.where(via, ik["swing_wt"][1], 0.0))
+            tasks[:, i, 5 * j + 1] = fid[j]
+            tasks[:, i, 5 * j + 2:5 * j + 5] = ref
+    tasks[:, :, 20] = ik["cent_wt"][0]
+    tasks[:, :, 24] = ik["cent_wt"][1]
+    tasks[:, :, 31] = ik["reg_wt"][0]
+    tasks[:, :, 32] = ik["reg_wt"][1]
+    x = np.concatenate([q, v], axis=1)
+    x_reg = np.concatenate([np.tile(SOLO12_Q0, (B, 1)), np.zeros((B, 18))], axis=1)
+    return WholeBodyBatch(dyn, x, T, tasks, ik["state_wt"][None].copy(), ik["ctrl_wt"][None].copy(), x_reg,
+                          ik["cent_wt"][0], ik["cent_wt"][1], fid)

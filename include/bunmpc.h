@@ -225,6 +225,18 @@ int bmpc_kinodyn_set_mom_tracking_weight(bmpc_kinodyn_t *h, double w);          
 int bmpc_kinodyn_compute_solve_times(bmpc_kinodyn_t *h);                                            /* :62 */
 int bmpc_kinodyn_return_solve_times(const bmpc_kinodyn_t *h, double *t3);  /* dyn, ik, total seconds  :63 */
 
+/* batch of KinoDynMP::optimize calls (additive), all pointers on the device:
+ *   x [B][37] = [q, v];  dyn.x_init [B][9] is OVERWRITTEN with [com, vcom, hg.angular] of x (kino_dyn.cpp:42),
+ *   dyn solved (use cold_start = 1 for set_warm_starts' behaviour), then the com / momentum
+ *   references of ik.tasks are OVERWRITTEN from dyn.X (kino_dyn.cpp:50-56; their weights are the
+ *   caller's wt_com / wt_mom already in the task blocks) and the IK-DDP runs. */
+typedef struct {
+    bmpc_batch_t dyn;
+    bmpc_ik_batch_t ik;
+    const double *x;
+} bmpc_kinodyn_batch_t;
+int bmpc_kinodyn_solve_batch_device(const bmpc_kinodyn_batch_t *d, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif
