@@ -97,6 +97,34 @@ def p50_latency(config, num_iters, reps=60):
     return float(np.median(ts[5:]) * 1e3)
 
 
+def kinodyn_leg(dev, B, admm_iters, maxit, steps=3):
+    """Informational: the full KinoDynMP.optimize (centroidal ADMM + whole-body IK-DDP, Solo12 trot,
+    H = 20, H_ik = 10) over B perturbed whole-body states, device resident."""
+    import torch
+    from bunmpc_amd import problems, urdf_model
+    from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
+    model = urdf_model.RobotModel.from_json(open(os.path.join(ROOT, "bunmpc_amd", "robots", "solo12.json")).read())
+    wb = problems.make_wb_batch(model, B)
+    kb = KinoDynDeviceBatch(wb, model, device=dev, num_iters=admm_iters, maxit=maxit)
+    kb.solve()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        kb.solve()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        kb.solve_ik_only()
+    torch.cuda.synchronize(dev)
+    dt_ik = (time.perf_counter() - t1) / steps
+    r = kb.results()
+    return {"value": B / dt, "unit": "KinoDynMP solves/s", "batch": B, "ms_per_step": dt * 1e3,
+            "ik_only_ms_per_step": dt_ik * 1e3, "ddp_iters_mean": float(r["ik_iters"].mean()),
+            "ddp_iters_max": int(r["ik_iters"].max()), "ddp_not_converged": int((r["ik_status"] != 0).sum()),
+            "admm_diverged": int((r["stats"][:, 5] != 0).sum())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +137,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=256)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-kinodyn", action="store_true")
+    ap.add_argument("--kinodyn-batch", type=int, default=4096)
     args = ap.parse_args()
 
     import torch
@@ -188,6 +218,8 @@ def main():
             out["speedup_vs_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["value"]
         if world == 1 and not args.no_latency:
             out["p50_latency_ms_batch1"] = p50_latency(args.config, args.admm_iters)
+        if world == 1 and not args.no_kinodyn:
+            out["kinodyn_full_solve"] = kinodyn_leg(dev, args.kinodyn_batch, args.admm_iters, args.maxit)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

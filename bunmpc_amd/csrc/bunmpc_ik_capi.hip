@@ -176,6 +176,8 @@ bmpc_model_t *bmpc_model_create(int nj, const int *parent, const double *R, cons
         h.parent[i] = parent[i];
         if (parent[i] >= i || parent[i] < -1) { delete m; ik_fail(BMPC_BAD_ARG, "joints must be listed parents first"); return nullptr; }
         std::memcpy(h.R[i], R + 9 * i, sizeof(double) * 9);
+        h.R_identity[i] = 1;
+        for (int c = 0; c < 9; ++c) if (R[9 * i + c] != (c % 4 == 0 ? 1.0 : 0.0)) h.R_identity[i] = 0;
         std::memcpy(h.p[i], p + 3 * i, sizeof(double) * 3);
         std::memcpy(h.axis[i], axis + 3 * i, sizeof(double) * 3);
     }
@@ -192,6 +194,9 @@ bmpc_model_t *bmpc_model_create(int nj, const int *parent, const double *R, cons
     for (int i = 0; i < nj; ++i)   // the subtree of joint i must be the contiguous index range i..chain_end[i]
         for (int j = i + 1; j <= h.chain_end[i]; ++j)
             if (parent[j] != j - 1) { delete m; ik_fail(BMPC_BAD_ARG, "chains must be numbered contiguously"); return nullptr; }
+    // the register-resident kinematics (rbd_quad.h) assume 4 legs of 3 joints: 3L hangs off the base, 3L+j off 3L+j-1
+    for (int i = 0; i < nj; ++i)
+        if (parent[i] != (i % 3 == 0 ? -1 : i - 1)) { delete m; ik_fail(BMPC_BAD_ARG, "expected 4 legs x 3 joints, numbered leg by leg"); return nullptr; }
     h.total_mass = 0;
     for (int b = 0; b <= nj; ++b) {
         h.mass[b] = mass[b]; h.total_mass += mass[b];

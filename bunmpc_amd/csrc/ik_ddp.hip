@@ -9,19 +9,21 @@
 //
 // MI355X organisation (nothing like crocoddyl's object graph): three kernels per DDP iteration over
 // the whole batch, all per-problem state in one contiguous HBM workspace (IkLayout):
-//   ik_calcdiff_kernel  one THREAD per (problem, node): kinematics, residuals, Gauss-Newton
-//                       L_x / L_xx, Euler Jacobian blocks.  B*(T+1) independent threads.
+//   ik_calcdiff_kernel  one WAVE per (problem, node): every lane runs the register-resident robot
+//                       pass (rbd_quad.h), lanes 0..17 each own one velocity column (CoM Jacobian,
+//                       A_g, dh_g/dq, frame Jacobians) written to LDS, then all 64 lanes assemble
+//                       the Gauss-Newton L_x / L_xx from those rows (coalesced 10 KB store).
 //   ik_backward_kernel  one WAVE per problem: Riccati recursion with V_xx, Q_xx, Q_xu, Q_uu, K held
-//                       in LDS (~50 KB/wave), exploiting F_x = [[A, dt B],[0, I]], F_u = [[dt^2 B],[dt I]]
+//                       in LDS (~53 KB/wave), exploiting F_x = [[A, dt B],[0, I]], F_u = [[dt^2 B],[dt I]]
 //                       (A, B identity except a 6x6 free-flyer block) so F^T V F costs O(n^2);
-//                       Cholesky and triangular solves cooperative across the 64 lanes;
+//                       Cholesky and triangular solves cooperative across the 64 lanes, in LDS;
 //                       regularisation retries inside the kernel.
 //   ik_forward_kernel   one WAVE per problem: line search 2^-k, k = 0..9 -- lanes 0..17 apply the
-//                       feedback u = u - a k - K dx, lane 0 rolls the node model forward; acceptance,
+//                       feedback u = u - a k - K dx, then the node cost / Euler step; acceptance,
 //                       regularisation update and stopping test as crocoddyl 1.9.0 solver-ddp.cpp.
 // The host loops over DDP iterations and stops when the device-side active counter reaches zero.
 #include "ik_types.h"
-#include "rbd_device.h"
+#include "rbd_quad.h"
 
 namespace bunmpc {
 namespace {
@@ -41,159 +43,63 @@ struct NodeTasks {
     __device__ double ctrl_w() const { return t[5 * kFrameSlots + 12]; }
 };
 
-// Cost of one node at (x, u) and, for running nodes, the Euler step.  With DIFF also L_x, L_xx
-// (to global memory, row-major 36x36), L_u, diag(L_uu) and the 6x6 blocks of F_x / F_u.
-// Running nodes: cost and derivatives scaled by dt (IntegratedActionModelEuler); terminal: unscaled, u = 0.
-template <bool DIFF>
-__device__ double node_eval(const RobotModelDev &m, const double *x, const double *u, const NodeTasks &tk,
-                            const double *state_w, const double *x_reg, const double *ctrl_w, double dt, bool terminal,
-                            double *xnext, double *Lx, double *Lxx, double *Lu, double *Luu, double *A6, double *B6) {
-    Kin k;
-    kin_compute<true>(m, x, k);
-    double cost = 0.0;
-    // Jacobian storage (DIFF only)
-    double Rm[6][kNDX];          // centroidal momentum: [dh/dq, A_g]
-    double Jc[3][kNV];           // CoM
-    double Jf[kFrameSlots][3][kNV];
-    double Jl[36];               // Jlog6 of the state residual's base block
-    double rm[6], rc[3], rf[kFrameSlots][3], rs[kNDX];
-    const double wm = tk.mom_w(), wc = tk.com_w(), ws = tk.state_w(), wu = tk.ctrl_w();
-    const bool has_mom = tk.mom_w() != 0.0 || DIFF;   // weight-0 costs contribute 0 either way
+struct Residuals { double rm[6], rc[3], rf[kFrameSlots][3]; };
 
-    // ---- residuals
-    for (int c = 0; c < 6; ++c) rm[c] = k.hg[c] - tk.mom_ref()[c];
-    for (int c = 0; c < 3; ++c) rc[c] = k.com[c] - tk.com_ref()[c];
-    cost += wm * 0.5 * (rm[0] * rm[0] + rm[1] * rm[1] + rm[2] * rm[2] + rm[3] * rm[3] + rm[4] * rm[4] + rm[5] * rm[5]);
-    cost += wc * 0.5 * dot3(rc, rc);
-    for (int s = 0; s < kFrameSlots; ++s) {
+// pass 1 + the residuals of the momentum / CoM / frame costs and their cost (unscaled, without the
+// state and control terms)
+template <bool COMPOSITE>
+__device__ __forceinline__ double kin_costs(const RobotModelDev &m, const double *x, const NodeTasks &tk, Pass1 &p1, Residuals &r) {
+    int fid[kFrameSlots];
+    UNROLL_RBD for (int s = 0; s < kFrameSlots; ++s) fid[s] = tk.frame_w(s) != 0.0 ? tk.frame_id(s) : -1;
+    quad_pass1<COMPOSITE>(m, x, fid, p1);
+    double cost = 0.0, a = 0.0;
+    UNROLL_RBD for (int c = 0; c < 6; ++c) { r.rm[c] = p1.hg[c] - tk.mom_ref()[c]; a += r.rm[c] * r.rm[c]; }
+    cost += tk.mom_w() * 0.5 * a;
+    UNROLL_RBD for (int c = 0; c < 3; ++c) r.rc[c] = p1.com[c] - tk.com_ref()[c];
+    cost += tk.com_w() * 0.5 * dot3(r.rc, r.rc);
+    UNROLL_RBD for (int s = 0; s < kFrameSlots; ++s) {
         const double w = tk.frame_w(s);
-        rf[s][0] = rf[s][1] = rf[s][2] = 0.0;
-        if (w != 0.0) {
-            double xf[3];
-            frame_position(m, k, tk.frame_id(s), xf);
-            for (int c = 0; c < 3; ++c) rf[s][c] = xf[c] - tk.frame_ref(s)[c];
-            cost += w * 0.5 * dot3(rf[s], rf[s]);
-        }
+        UNROLL_RBD for (int c = 0; c < 3; ++c) r.rf[s][c] = w != 0.0 ? p1.fx[s][c] - tk.frame_ref(s)[c] : 0.0;
+        cost += w * 0.5 * dot3(r.rf[s], r.rf[s]);
     }
-    if (ws != 0.0) {
-        state_diff<DIFF>(x_reg, x, rs, Jl);
-        double a = 0.0;
-        for (int i = 0; i < kNDX; ++i) a += state_w[i] * rs[i] * rs[i];
-        cost += ws * 0.5 * a;
-    } else {
-        for (int i = 0; i < kNDX; ++i) rs[i] = 0.0;
-        if (DIFF) { for (int i = 0; i < 36; ++i) Jl[i] = (i % 7 == 0) ? 1.0 : 0.0; }
-    }
-    if (!terminal && wu != 0.0) {
-        double a = 0.0;
-        for (int i = 0; i < kNV; ++i) a += ctrl_w[i] * u[i] * u[i];
-        cost += wu * 0.5 * a;
-    }
-    (void)has_mom;
+    return cost;
+}
 
-    if (DIFF) {
-        // ---- subtree composites / momenta per joint (serial chains), whole robot for the base columns
-        Comp call; comp_zero(call);
-        for (int b = 0; b <= m.nj; ++b) comp_add(call, k.body[b]);
-        for (int col = 0; col < kNV; ++col) {
-            Comp cs; double hs[6];
-            if (col < 6) { cs = call; for (int c = 0; c < 6; ++c) hs[c] = k.hO[c]; }
-            else {
-                comp_zero(cs);
-                for (int c = 0; c < 6; ++c) hs[c] = 0.0;
-                for (int j = col - 6; j <= m.chain_end[col - 6]; ++j) {
-                    comp_add(cs, k.body[j + 1]);
-                    for (int c = 0; c < 6; ++c) hs[c] += k.hb[j + 1][c];
-                }
-            }
-            const double *S = k.S[col];
-            double h[6], t3[3];
-            comp_apply(cs, S, h);                       // (l, n_O) of the subtree moved by this column
-            for (int c = 0; c < 3; ++c) Jc[c][col] = h[c] / k.M;
-            cross3(k.com, h, t3);
-            for (int c = 0; c < 3; ++c) { Rm[c][kNV + col] = h[c]; Rm[3 + c][kNV + col] = h[3 + c] - t3[c]; }
-            // d h_O / d q_col = S x* h_sub - I_sub (S x V_parent)
-            double cf[6], sxv[6], ih[6], a3[3], b3[3];
-            cross3(S + 3, hs, cf);
-            cross3(S + 3, hs + 3, a3); cross3(S, hs, b3);
-            for (int c = 0; c < 3; ++c) cf[3 + c] = a3[c] + b3[c];
-            if (col < 6) { for (int c = 0; c < 6; ++c) sxv[c] = 0.0; }
-            else {
-                const double *Vp = k.V[m.parent[col - 6] + 1];
-                cross3(S + 3, Vp, a3); cross3(S, Vp + 3, b3);
-                for (int c = 0; c < 3; ++c) sxv[c] = a3[c] + b3[c];
-                cross3(S + 3, Vp + 3, sxv + 3);
-            }
-            comp_apply(cs, sxv, ih);
-            double dO[6];
-            for (int c = 0; c < 6; ++c) dO[c] = cf[c] - ih[c];
-            const double jc[3] = {Jc[0][col], Jc[1][col], Jc[2][col]};
-            cross3(jc, k.hO, a3); cross3(k.com, dO, b3);
-            for (int c = 0; c < 3; ++c) { Rm[c][col] = dO[c]; Rm[3 + c][col] = dO[3 + c] - a3[c] - b3[c]; }
-        }
-        for (int s = 0; s < kFrameSlots; ++s) {
-            const bool on = tk.frame_w(s) != 0.0;
-            double xf[3] = {0, 0, 0};
-            int fb = 0;
-            if (on) { frame_position(m, k, tk.frame_id(s), xf); fb = m.frame_body[tk.frame_id(s)]; }
-            for (int col = 0; col < kNV; ++col) {
-                double j3[3] = {0, 0, 0};
-                if (on && in_support(m, fb, col)) {
-                    cross3(k.S[col] + 3, xf, j3);
-                    for (int c = 0; c < 3; ++c) j3[c] += k.S[col][c];
-                }
-                for (int c = 0; c < 3; ++c) Jf[s][c][col] = j3[c];
-            }
-        }
-        // ---- L_x
-        const double sc = terminal ? 1.0 : dt;
-        for (int i = 0; i < kNDX; ++i) {
-            double g = 0.0;
-            for (int r = 0; r < 6; ++r) g += Rm[r][i] * rm[r];
-            g *= wm;
-            if (i < kNV) {
-                g += wc * (Jc[0][i] * rc[0] + Jc[1][i] * rc[1] + Jc[2][i] * rc[2]);
-                for (int s = 0; s < kFrameSlots; ++s)
-                    g += tk.frame_w(s) * (Jf[s][0][i] * rf[s][0] + Jf[s][1][i] * rf[s][1] + Jf[s][2][i] * rf[s][2]);
-            }
-            if (i < 6) { double a = 0.0; for (int r = 0; r < 6; ++r) a += Jl[6 * r + i] * state_w[r] * rs[r]; g += ws * a; }
-            else g += ws * state_w[i] * rs[i];
-            Lx[i] = sc * g;
-        }
-        // ---- L_xx (Gauss-Newton), symmetric
-        for (int i = 0; i < kNDX; ++i)
-            for (int j = i; j < kNDX; ++j) {
-                double h = 0.0;
-                for (int r = 0; r < 6; ++r) h += Rm[r][i] * Rm[r][j];
-                h *= wm;
-                if (j < kNV) {
-                    h += wc * (Jc[0][i] * Jc[0][j] + Jc[1][i] * Jc[1][j] + Jc[2][i] * Jc[2][j]);
-                    for (int s = 0; s < kFrameSlots; ++s)
-                        h += tk.frame_w(s) * (Jf[s][0][i] * Jf[s][0][j] + Jf[s][1][i] * Jf[s][1][j] + Jf[s][2][i] * Jf[s][2][j]);
-                }
-                if (j < 6) { double a = 0.0; for (int r = 0; r < 6; ++r) a += Jl[6 * r + i] * state_w[r] * Jl[6 * r + j]; h += ws * a; }
-                else if (i == j) h += ws * state_w[i];
-                h *= sc;
-                Lxx[i * kNDX + j] = h;
-                Lxx[j * kNDX + i] = h;
-            }
-        if (!terminal) {
-            for (int i = 0; i < kNV; ++i) { Lu[i] = sc * wu * ctrl_w[i] * u[i]; Luu[i] = sc * wu * ctrl_w[i]; }
-        }
+// IntegratedActionModelEuler: dx = [v dt + u dt^2 ; u dt], xnext = x (+) dx; optionally the 6x6 blocks of
+// Jintegrate (w.r.t. x: A6, w.r.t. dx: B6)
+template <bool JAC>
+__device__ __forceinline__ void euler_step(const double *x, const double *u, double dt, double *xnext, double *A6, double *B6) {
+    double dx[kNDX];
+    const double *v = x + kNQ;
+    UNROLL_RBD for (int i = 0; i < kNV; ++i) { dx[i] = v[i] * dt + u[i] * dt * dt; dx[kNV + i] = u[i] * dt; }
+    state_integrate(x, dx, xnext);
+    if (JAC) {
+        double dR[9], dp[3];
+        exp6(dx, dR, dp);
+        act_inv(dR, dp, A6);
+        jexp6(dx, B6);
     }
-    if (!terminal) {
-        double dx[kNDX];
-        const double *v = x + kNQ;
-        for (int i = 0; i < kNV; ++i) { dx[i] = v[i] * dt + u[i] * dt * dt; dx[kNV + i] = u[i] * dt; }
-        state_integrate(x, dx, xnext);
-        if (DIFF) {
-            double dR[9], dp[3];
-            exp6(dx, dR, dp);
-            act_inv(dR, dp, A6);   // Jintegrate w.r.t. x   (free-flyer block)
-            jexp6(dx, B6);         // Jintegrate w.r.t. dx  (free-flyer block)
-        }
+}
+
+// node cost at (x, u) and the Euler step (forward pass); x, u may live in LDS
+__device__ __forceinline__ double node_cost(const RobotModelDev &m, const double *x, const double *u, const NodeTasks &tk, const double *state_w,
+                            const double *x_reg, const double *ctrl_w, double dt, bool terminal, double *xnext) {
+    Pass1 p1; Residuals r;
+    double cost = kin_costs<false>(m, x, tk, p1, r);
+    if (tk.state_w() != 0.0) {
+        double rs[kNDX], a = 0.0;
+        state_diff<false>(x_reg, x, rs, nullptr);
+        UNROLL_RBD for (int i = 0; i < kNDX; ++i) a += state_w[i] * rs[i] * rs[i];
+        cost += tk.state_w() * 0.5 * a;
     }
-    return terminal ? cost : dt * cost;
+    if (terminal) return cost;
+    if (tk.ctrl_w() != 0.0) {
+        double a = 0.0;
+        UNROLL_RBD for (int i = 0; i < kNV; ++i) a += ctrl_w[i] * u[i] * u[i];
+        cost += tk.ctrl_w() * 0.5 * a;
+    }
+    euler_step<false>(x, u, dt, xnext, nullptr, nullptr);
+    return dt * cost;
 }
 
 __device__ const double *batch_ptr(const double *p, long stride, long b) { return p + stride * b; }
@@ -219,29 +125,116 @@ __global__ void ik_init_kernel(const IkBatchArgs a) {
 }
 
 // --------------------------------------------------------------------------- calcDiff ---
+struct CalcLds {
+    RobotModelDev m;
+    double x[kNX], u[kNV];
+    double Rm[6][kNDX];               // centroidal momentum rows [dh/dq, A_g]
+    double Jc[3][kNV];                // CoM rows
+    double Jf[kFrameSlots][3][kNV];   // frame rows
+    double rs[kNDX], Jl[36];          // state residual and the Jlog6 block of its Jacobian
+};
+
 __global__ __launch_bounds__(64) void ik_calcdiff_kernel(const IkBatchArgs a) {
-    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ CalcLds s;
     const int nn = a.T + 1;
-    if (id >= (long)a.B * nn) return;
-    const long b = id / nn;
-    const int t = (int)(id % nn);
+    const long b = blockIdx.x / nn;
+    const int t = blockIdx.x % nn, lane = threadIdx.x;
     const IkLayout L = IkLayout::make(a.T);
     double *ws = a.ws + b * L.total;
     if (ws[L.scal + S_DONE] != 0.0 || ws[L.scal + S_RECALC] == 0.0) return;
     const bool terminal = t == a.T;
+    {
+        const int *src = reinterpret_cast<const int *>(a.model);
+        int *dst = reinterpret_cast<int *>(&s.m);
+        for (int i = lane; i < (int)(sizeof(RobotModelDev) / sizeof(int)); i += 64) dst[i] = src[i];
+    }
+    const RobotModelDev &m = s.m;
     NodeTasks tk{a.tasks + (b * nn + t) * kNodeTaskDoubles};
-    double xnext[kNX], Lx[kNDX], Lu[kNV], Luu[kNV], A6[36], B6[36];
+    const double *state_w = batch_ptr(a.state_w, a.s_state_w, b), *ctrl_w = batch_ptr(a.ctrl_w, a.s_ctrl_w, b);
     const double dt = terminal ? 0.0 : a.dt[b * a.T + t];
-    const double c = node_eval<true>(*a.model, ws + L.xs + (long)t * kNX, terminal ? nullptr : ws + L.us + (long)t * kNV, tk,
-                                     batch_ptr(a.state_w, a.s_state_w, b), a.x_reg + b * kNX, batch_ptr(a.ctrl_w, a.s_ctrl_w, b),
-                                     dt, terminal, xnext, Lx, ws + L.Lxx + (long)t * kNDX * kNDX, Lu, Luu, A6, B6);
-    for (int i = 0; i < kNDX; ++i) ws[L.Lx + (long)t * kNDX + i] = Lx[i];
-    // node costs are summed by the backward kernel: parked in the (not yet used) fs slot of this node
-    ws[L.fs + (long)t * kNDX] = c;
-    if (!terminal) {
-        for (int i = 0; i < kNV; ++i) { ws[L.Lu + (long)t * kNV + i] = Lu[i]; ws[L.Luu + (long)t * kNV + i] = Luu[i]; }
-        for (int i = 0; i < 36; ++i) { ws[L.A6 + (long)t * 36 + i] = A6[i]; ws[L.B6 + (long)t * 36 + i] = B6[i]; }
-        for (int i = 0; i < kNX; ++i) ws[L.xnext + (long)t * kNX + i] = xnext[i];
+    if (lane < kNX) s.x[lane] = ws[L.xs + (long)t * kNX + lane];
+    if (lane < kNV) s.u[lane] = terminal ? 0.0 : ws[L.us + (long)t * kNV + lane];
+    __syncthreads();
+    Pass1 p1; Residuals r;
+    double cost = kin_costs<true>(m, s.x, tk, p1, r);     // every lane: the same robot pass, in registers
+    const double wm = tk.mom_w(), wc = tk.com_w(), wst = tk.state_w(), wu = tk.ctrl_w();
+    if (lane < kNV) {   // one velocity column per lane
+        Column c;
+        quad_column(m, s.x, p1, lane, c);
+        UNROLL_RBD for (int k = 0; k < 3; ++k) s.Jc[k][lane] = c.jc[k];
+        UNROLL_RBD for (int k = 0; k < 6; ++k) { s.Rm[k][lane] = c.dh[k]; s.Rm[k][kNV + lane] = c.ag[k]; }
+        UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) {
+            double j3[3] = {0, 0, 0};
+            if (tk.frame_w(f) != 0.0 && quad_supports(m, tk.frame_id(f), lane)) {
+                cross3(c.S + 3, p1.fx[f], j3);
+                UNROLL_RBD for (int k = 0; k < 3; ++k) j3[k] += c.S[k];
+            }
+            UNROLL_RBD for (int k = 0; k < 3; ++k) s.Jf[f][k][lane] = j3[k];
+        }
+    } else if (lane == 32) {   // state residual + its Jacobian block, Euler step, node cost
+        double rs[kNDX], Jl[36];
+        if (wst != 0.0) {
+            state_diff<true>(a.x_reg + b * kNX, s.x, rs, Jl);
+            double acc = 0.0;
+            UNROLL_RBD for (int i = 0; i < kNDX; ++i) acc += state_w[i] * rs[i] * rs[i];
+            cost += wst * 0.5 * acc;
+        } else {
+            UNROLL_RBD for (int i = 0; i < kNDX; ++i) rs[i] = 0.0;
+            UNROLL_RBD for (int i = 0; i < 36; ++i) Jl[i] = (i % 7 == 0) ? 1.0 : 0.0;
+        }
+        UNROLL_RBD for (int i = 0; i < kNDX; ++i) s.rs[i] = rs[i];
+        UNROLL_RBD for (int i = 0; i < 36; ++i) s.Jl[i] = Jl[i];
+        if (!terminal) {
+            double acc = 0.0;
+            UNROLL_RBD for (int i = 0; i < kNV; ++i) acc += ctrl_w[i] * s.u[i] * s.u[i];
+            cost += wu * 0.5 * acc;
+            double xn[kNX], A6[36], B6[36];
+            euler_step<true>(s.x, s.u, dt, xn, A6, B6);
+            UNROLL_RBD for (int i = 0; i < kNX; ++i) ws[L.xnext + (long)t * kNX + i] = xn[i];
+            UNROLL_RBD for (int i = 0; i < 36; ++i) { ws[L.A6 + (long)t * 36 + i] = A6[i]; ws[L.B6 + (long)t * 36 + i] = B6[i]; }
+            cost *= dt;
+        }
+        // node costs are summed by the backward kernel: parked in the fs slot of this node
+        ws[L.fs + (long)t * kNDX] = cost;
+    }
+    __syncthreads();
+    const double sc = terminal ? 1.0 : dt;
+    // L_x
+    if (lane < kNDX) {
+        const int i = lane;
+        double g = 0.0;
+        UNROLL_RBD for (int k = 0; k < 6; ++k) g += s.Rm[k][i] * r.rm[k];
+        g *= wm;
+        if (i < kNV) {
+            g += wc * (s.Jc[0][i] * r.rc[0] + s.Jc[1][i] * r.rc[1] + s.Jc[2][i] * r.rc[2]);
+            UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
+                g += tk.frame_w(f) * (s.Jf[f][0][i] * r.rf[f][0] + s.Jf[f][1][i] * r.rf[f][1] + s.Jf[f][2][i] * r.rf[f][2]);
+        }
+        if (i < 6) { double acc = 0.0; for (int k = 0; k < 6; ++k) acc += s.Jl[6 * k + i] * state_w[k] * s.rs[k]; g += wst * acc; }
+        else g += wst * state_w[i] * s.rs[i];
+        ws[L.Lx + (long)t * kNDX + i] = sc * g;
+    }
+    // L_xx (Gauss-Newton): every lane ~20 entries, rows read from LDS, coalesced store
+    double *Lxx = ws + L.Lxx + (long)t * kNDX * kNDX;
+    double fw[kFrameSlots];
+    UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) fw[f] = tk.frame_w(f);
+    for (int e = lane; e < kNDX * kNDX; e += 64) {
+        const int i = e / kNDX, j = e % kNDX;
+        double h = 0.0;
+        UNROLL_RBD for (int k = 0; k < 6; ++k) h += s.Rm[k][i] * s.Rm[k][j];
+        h *= wm;
+        if (i < kNV && j < kNV) {
+            h += wc * (s.Jc[0][i] * s.Jc[0][j] + s.Jc[1][i] * s.Jc[1][j] + s.Jc[2][i] * s.Jc[2][j]);
+            UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
+                h += fw[f] * (s.Jf[f][0][i] * s.Jf[f][0][j] + s.Jf[f][1][i] * s.Jf[f][1][j] + s.Jf[f][2][i] * s.Jf[f][2][j]);
+        }
+        if (i < 6 && j < 6) { double acc = 0.0; for (int k = 0; k < 6; ++k) acc += s.Jl[6 * k + i] * state_w[k] * s.Jl[6 * k + j]; h += wst * acc; }
+        else if (i == j) h += wst * state_w[i];
+        Lxx[e] = sc * h;
+    }
+    if (!terminal && lane < kNV) {
+        ws[L.Lu + (long)t * kNV + lane] = sc * wu * ctrl_w[lane] * s.u[lane];
+        ws[L.Luu + (long)t * kNV + lane] = sc * wu * ctrl_w[lane];
     }
 }
 
@@ -269,10 +262,8 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
     const bool wasfeas = sc[S_WASFEAS] != 0.0;
 
     if (sc[S_RECALC] != 0.0) {
-        // SolverDDP::calcDiff tail: total cost and the gaps fs (solver-ddp.cpp calcDiff)
-        __syncthreads();
-        double c = 0.0;
-        if (lane == 0) { for (int t = 0; t <= T; ++t) c += ws[L.fs + (long)t * kNDX]; sc[S_COST] = c; }
+        // SolverDDP::calcDiff tail: total cost and the gaps fs
+        if (lane == 0) { double c = 0.0; for (int t = 0; t <= T; ++t) c += ws[L.fs + (long)t * kNDX]; sc[S_COST] = c; }
         __syncthreads();
         if (!feas) {
             double mx = 0.0;
@@ -281,7 +272,7 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
                 const double *xa = ws + L.xs + (long)lane * kNX;
                 const double *xb = lane == 0 ? a.x0 + b * kNX : ws + L.xnext + (long)(lane - 1) * kNX;
                 state_diff<false>(xa, xb, d, nullptr);
-                for (int i = 0; i < kNDX; ++i) { ws[L.fs + (long)lane * kNDX + i] = d[i]; mx = fmax(mx, fabs(d[i])); }
+                UNROLL_RBD for (int i = 0; i < kNDX; ++i) { ws[L.fs + (long)lane * kNDX + i] = d[i]; mx = fmax(mx, fabs(d[i])); }
             }
             const bool ok = __all(mx < 1e-16);   // th_gaptol_
             feas = ok;
@@ -289,8 +280,7 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
         } else if (!wasfeas) {
             for (long i = lane; i < (long)(T + 1) * kNDX; i += 64) ws[L.fs + i] = 0.0;
         } else {
-            // fs slots were used to park node costs: restore zeros
-            if (lane <= T) ws[L.fs + (long)lane * kNDX] = 0.0;
+            if (lane <= T) ws[L.fs + (long)lane * kNDX] = 0.0;   // the parked node costs
         }
         __syncthreads();
     }
@@ -298,7 +288,6 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
     double xreg = sc[S_XREG];
     for (;;) {   // computeDirection with regularisation retries (solver-ddp.cpp solve())
         if (lane == 0) s.flag = 0;
-        // terminal node
         for (int e = lane; e < kNDX * kNDX; e += 64) {
             const int i = e / kNDX, j = e % kNDX;
             s.V[i * LD + j] = ws[L.Lxx + (long)T * kNDX * kNDX + e] + (i == j ? xreg : 0.0);
@@ -326,9 +315,9 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             for (int e = lane; e < kNDX * kNDX; e += 64) {
                 const int i = e / kNDX, j = e % kNDX;
                 double v;
-                if (i < 6) { v = 0.0; for (int c = 0; c < 6; ++c) v += s.A6[6 * c + i] * s.V[c * LD + j]; }
+                if (i < 6) { v = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) v += s.A6[6 * c + i] * s.V[c * LD + j]; }
                 else if (i < kNV) v = s.V[i * LD + j];
-                else if (i < kNV + 6) { v = 0.0; for (int c = 0; c < 6; ++c) v += s.B6[6 * c + (i - kNV)] * s.V[c * LD + j]; v = dt * v + s.V[i * LD + j]; }
+                else if (i < kNV + 6) { v = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) v += s.B6[6 * c + (i - kNV)] * s.V[c * LD + j]; v = dt * v + s.V[i * LD + j]; }
                 else v = dt * s.V[(i - kNV) * LD + j] + s.V[i * LD + j];
                 s.M1[i * LD + j] = v;
             }
@@ -336,16 +325,16 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             if (lane < kNDX) {
                 const int i = lane;
                 double v;
-                if (i < 6) { v = 0.0; for (int c = 0; c < 6; ++c) v += s.A6[6 * c + i] * s.Vx[c]; }
+                if (i < 6) { v = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) v += s.A6[6 * c + i] * s.Vx[c]; }
                 else if (i < kNV) v = s.Vx[i];
-                else if (i < kNV + 6) { v = 0.0; for (int c = 0; c < 6; ++c) v += s.B6[6 * c + (i - kNV)] * s.Vx[c]; v = dt * v + s.Vx[i]; }
+                else if (i < kNV + 6) { v = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) v += s.B6[6 * c + (i - kNV)] * s.Vx[c]; v = dt * v + s.Vx[i]; }
                 else v = dt * s.Vx[i - kNV] + s.Vx[i];
                 s.Qx[i] = ws[L.Lx + (long)t * kNDX + i] + v;
             }
             if (lane < kNV) {
                 const int q = lane;
                 double v;
-                if (q < 6) { v = 0.0; for (int c = 0; c < 6; ++c) v += s.B6[6 * c + q] * s.Vx[c]; } else v = s.Vx[q];
+                if (q < 6) { v = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) v += s.B6[6 * c + q] * s.Vx[c]; } else v = s.Vx[q];
                 s.Qu[q] = ws[L.Lu + (long)t * kNV + q] + dt2 * v + dt * s.Vx[kNV + q];
             }
             __syncthreads();
@@ -353,9 +342,9 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             for (int e = lane; e < kNDX * kNDX; e += 64) {
                 const int i = e / kNDX, j = e % kNDX;
                 double v;
-                if (j < 6) { v = 0.0; for (int c = 0; c < 6; ++c) v += s.M1[i * LD + c] * s.A6[6 * c + j]; }
+                if (j < 6) { v = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) v += s.M1[i * LD + c] * s.A6[6 * c + j]; }
                 else if (j < kNV) v = s.M1[i * LD + j];
-                else if (j < kNV + 6) { v = 0.0; for (int c = 0; c < 6; ++c) v += s.M1[i * LD + c] * s.B6[6 * c + (j - kNV)]; v = dt * v + s.M1[i * LD + j]; }
+                else if (j < kNV + 6) { v = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) v += s.M1[i * LD + c] * s.B6[6 * c + (j - kNV)]; v = dt * v + s.M1[i * LD + j]; }
                 else v = dt * s.M1[i * LD + (j - kNV)] + s.M1[i * LD + j];
                 s.W[i * LD + j] += v;
             }
@@ -364,7 +353,7 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
                 double v1, v2;
                 if (q < 6) {
                     v1 = 0.0; v2 = 0.0;
-                    for (int c = 0; c < 6; ++c) { v1 += s.M1[i * LD + c] * s.B6[6 * c + q]; v2 += s.V[i * LD + c] * s.B6[6 * c + q]; }
+                    UNROLL_RBD for (int c = 0; c < 6; ++c) { v1 += s.M1[i * LD + c] * s.B6[6 * c + q]; v2 += s.V[i * LD + c] * s.B6[6 * c + q]; }
                 } else { v1 = s.M1[i * LD + q]; v2 = s.V[i * LD + q]; }
                 s.Qxu[i * LDU + q] = dt2 * v1 + dt * s.M1[i * LD + kNV + q];
                 s.VFu[i * LDU + q] = dt2 * v2 + dt * s.V[i * LD + kNV + q];
@@ -374,7 +363,7 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             for (int e = lane; e < kNV * kNV; e += 64) {
                 const int p = e / kNV, q = e % kNV;
                 double v;
-                if (p < 6) { v = 0.0; for (int c = 0; c < 6; ++c) v += s.B6[6 * c + p] * s.VFu[c * LDU + q]; } else v = s.VFu[p * LDU + q];
+                if (p < 6) { v = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) v += s.B6[6 * c + p] * s.VFu[c * LDU + q]; } else v = s.VFu[p * LDU + q];
                 v = dt2 * v + dt * s.VFu[(kNV + p) * LDU + q];
                 if (p == q) v += s.Luu[p] + xreg;
                 s.Quu[p * LDU + q] = v;
@@ -395,21 +384,21 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
                 }
                 __syncthreads();
             }
-            // K = Quu^-1 Qxu^T (one right-hand side per lane), k = Quu^-1 Qu (lane 36)
+            // K = Quu^-1 Qxu^T: lane j < 36 solves for column j (18 unknowns in registers); lane 36: k = Quu^-1 Qu
             if (lane <= kNDX) {
                 double y[kNV];
-                for (int p = 0; p < kNV; ++p) {
+                UNROLL_RBD for (int p = 0; p < kNV; ++p) {
                     double v = lane < kNDX ? s.Qxu[lane * LDU + p] : s.Qu[p];
-                    for (int q = 0; q < p; ++q) v -= s.Quu[p * LDU + q] * y[q];
+                    UNROLL_RBD for (int q = 0; q < p; ++q) v -= s.Quu[p * LDU + q] * y[q];
                     y[p] = v / s.Quu[p * LDU + p];
                 }
-                for (int p = kNV - 1; p >= 0; --p) {
+                UNROLL_RBD for (int p = kNV - 1; p >= 0; --p) {
                     double v = y[p];
-                    for (int q = p + 1; q < kNV; ++q) v -= s.Quu[q * LDU + p] * y[q];
+                    UNROLL_RBD for (int q = p + 1; q < kNV; ++q) v -= s.Quu[q * LDU + p] * y[q];
                     y[p] = v / s.Quu[p * LDU + p];
                 }
-                if (lane < kNDX) { for (int p = 0; p < kNV; ++p) s.Kt[p * LD + lane] = y[p]; }
-                else { for (int p = 0; p < kNV; ++p) s.kf[p] = y[p]; }
+                if (lane < kNDX) { UNROLL_RBD for (int p = 0; p < kNV; ++p) s.Kt[p * LD + lane] = y[p]; }
+                else { UNROLL_RBD for (int p = 0; p < kNV; ++p) s.kf[p] = y[p]; }
             }
             __syncthreads();
             // Quuk = Quu k = L (L^T k)
@@ -424,26 +413,26 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             }
             for (int e = lane; e < kNV * kNDX; e += 64) ws[L.K + (long)t * kNV * kNDX + e] = s.Kt[(e / kNDX) * LD + e % kNDX];
             // Vx = Qx - K^T Qu ; Vxx = Qxx - Qxu K (into M1), then symmetrise + xreg
-            if (lane < kNDX) { double v = s.Qx[lane]; for (int p = 0; p < kNV; ++p) v -= s.Kt[p * LD + lane] * s.Qu[p]; s.Vx[lane] = v; }
+            if (lane < kNDX) { double v = s.Qx[lane]; UNROLL_RBD for (int p = 0; p < kNV; ++p) v -= s.Kt[p * LD + lane] * s.Qu[p]; s.Vx[lane] = v; }
             for (int e = lane; e < kNDX * kNDX; e += 64) {
                 const int i = e / kNDX, j = e % kNDX;
                 double v = s.W[i * LD + j];
-                for (int p = 0; p < kNV; ++p) v -= s.Qxu[i * LDU + p] * s.Kt[p * LD + j];
+                UNROLL_RBD for (int p = 0; p < kNV; ++p) v -= s.Qxu[i * LDU + p] * s.Kt[p * LD + j];
                 s.M1[i * LD + j] = v;
             }
             __syncthreads();
+            bool bad = false;
             for (int e = lane; e < kNDX * kNDX; e += 64) {
                 const int i = e / kNDX, j = e % kNDX;
-                s.V[i * LD + j] = 0.5 * (s.M1[i * LD + j] + s.M1[j * LD + i]) + (i == j ? xreg : 0.0);
+                const double v = 0.5 * (s.M1[i * LD + j] + s.M1[j * LD + i]) + (i == j ? xreg : 0.0);
+                s.V[i * LD + j] = v;
+                bad = bad || !(fabs(v) < INFINITY);
             }
             __syncthreads();
             if (!feas && lane < kNDX) { double acc = 0.0; for (int j = 0; j < kNDX; ++j) acc += s.V[lane * LD + j] * s.fs[j]; s.tmp[lane] = s.Vx[lane] + acc; }
             __syncthreads();
             if (!feas && lane < kNDX) s.Vx[lane] = s.tmp[lane];
-            // raiseIfNaN on Vx / Vxx
-            bool bad = false;
-            if (lane < kNDX) bad = !(fabs(s.Vx[lane]) < INFINITY);
-            for (int e = lane; e < kNDX * kNDX; e += 64) bad = bad || !(fabs(s.V[(e / kNDX) * LD + e % kNDX]) < INFINITY);
+            if (lane < kNDX) bad = bad || !(fabs(s.Vx[lane]) < INFINITY);   // raiseIfNaN on Vx / Vxx
             if (__any(bad) && lane == 0) s.flag = 1;
             __syncthreads();
             if (s.flag) break;
@@ -460,19 +449,17 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
         __syncthreads();
     }
     // expectedImprovement / stoppingCriteria ingredients
-    if (lane == 0) {
-        double d1 = 0.0, d2 = 0.0, st = 0.0;
-        for (int t = 0; t < T; ++t)
-            for (int p = 0; p < kNV; ++p) {
-                const double qu = ws[L.Qu + (long)t * kNV + p], kk = ws[L.kff + (long)t * kNV + p];
-                d1 += qu * kk; d2 -= kk * ws[L.Quuk + (long)t * kNV + p]; st += qu * qu;
-            }
-        sc[S_D1] = d1; sc[S_D2] = d2; sc[S_STOP] = st;
+    double d1 = 0.0, d2 = 0.0, st = 0.0;
+    for (int e = lane; e < T * kNV; e += 64) {
+        const double qu = ws[L.Qu + e], kk = ws[L.kff + e];
+        d1 += qu * kk; d2 -= kk * ws[L.Quuk + e]; st += qu * qu;
     }
+    for (int off = 32; off > 0; off >>= 1) { d1 += __shfl_down(d1, off); d2 += __shfl_down(d2, off); st += __shfl_down(st, off); }
+    if (lane == 0) { sc[S_D1] = d1; sc[S_D2] = d2; sc[S_STOP] = st; }
 }
 
 // ---------------------------------------------------------------------------- forward ---
-struct ForwardLds { double dx[kNDX], u[kNV], x[kNX]; double bc[4]; };
+struct ForwardLds { RobotModelDev m; double dx[kNDX], u[kNV], x[kNX]; double bc[4]; };
 
 __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
     __shared__ ForwardLds s;
@@ -483,6 +470,13 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
     double *sc = ws + L.scal;
     if (sc[S_DONE] != 0.0) return;
     const int T = a.T, nn = a.T + 1;
+    {   // the robot model is read many times per node: stage it in LDS once
+        const int *src = reinterpret_cast<const int *>(a.model);
+        int *dst = reinterpret_cast<int *>(&s.m);
+        for (int i = lane; i < (int)(sizeof(RobotModelDev) / sizeof(int)); i += 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    const RobotModelDev &m = s.m;
     const double cost = sc[S_COST], d1 = sc[S_D1], d2 = sc[S_D2];
     const bool feas = sc[S_FEAS] != 0.0;
     const double *state_w = batch_ptr(a.state_w, a.s_state_w, b), *ctrl_w = batch_ptr(a.ctrl_w, a.s_ctrl_w, b);
@@ -493,42 +487,34 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
         alpha = ldexp(1.0, -ia);
         bool failed = false;
         cost_try = 0.0;
-        for (int t = 0; t < T && !failed; ++t) {
-            if (lane == 0) {
-                state_diff<false>(ws + L.xs + (long)t * kNX, ws + L.xs_try + (long)t * kNX, s.dx, nullptr);
-                for (int i = 0; i < kNX; ++i) s.x[i] = ws[L.xs_try + (long)t * kNX + i];
+        if (lane < kNX) s.x[lane] = ws[L.xs_try + lane];
+        __syncthreads();
+        for (int t = 0; t <= T && !failed; ++t) {   // t == T: terminal node (cost only)
+            const bool terminal = t == T;
+            if (!terminal) {
+                if (lane == 0) state_diff<false>(ws + L.xs + (long)t * kNX, s.x, s.dx, nullptr);
+                __syncthreads();
+                if (lane < kNV) {
+                    const double *Kr = ws + L.K + (long)t * kNV * kNDX + (long)lane * kNDX;
+                    double v = ws[L.us + (long)t * kNV + lane] - alpha * ws[L.kff + (long)t * kNV + lane];
+                    UNROLL_RBD for (int j = 0; j < kNDX; ++j) v -= Kr[j] * s.dx[j];
+                    s.u[lane] = v;
+                    ws[L.us_try + (long)t * kNV + lane] = v;
+                }
+                __syncthreads();
             }
-            __syncthreads();
-            if (lane < kNV) {
-                const double *Kr = ws + L.K + (long)t * kNV * kNDX + (long)lane * kNDX;
-                double v = ws[L.us + (long)t * kNV + lane] - alpha * ws[L.kff + (long)t * kNV + lane];
-                for (int j = 0; j < kNDX; ++j) v -= Kr[j] * s.dx[j];
-                s.u[lane] = v;
-                ws[L.us_try + (long)t * kNV + lane] = v;
-            }
-            __syncthreads();
+            double xn[kNX];
             if (lane == 0) {
                 NodeTasks tk{a.tasks + (b * nn + t) * kNodeTaskDoubles};
-                double xn[kNX];
-                const double c = node_eval<false>(*a.model, s.x, s.u, tk, state_w, x_reg, ctrl_w, a.dt[b * T + t], false, xn,
-                                                  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+                const double c = node_cost(m, s.x, s.u, tk, state_w, x_reg, ctrl_w, terminal ? 0.0 : a.dt[b * T + t], terminal, xn);
                 bool bad = !(fabs(c) < INFINITY);
-                for (int i = 0; i < kNX; ++i) { ws[L.xs_try + (long)(t + 1) * kNX + i] = xn[i]; bad = bad || !(fabs(xn[i]) < INFINITY); }
+                if (!terminal) {
+                    UNROLL_RBD for (int i = 0; i < kNX; ++i) { ws[L.xs_try + (long)(t + 1) * kNX + i] = xn[i]; bad = bad || !(fabs(xn[i]) < INFINITY); }
+                }
                 s.bc[0] = c; s.bc[1] = bad ? 1.0 : 0.0;
             }
             __syncthreads();
-            cost_try += s.bc[0];
-            failed = s.bc[1] != 0.0;
-            __syncthreads();
-        }
-        if (!failed) {
-            if (lane == 0) {
-                NodeTasks tk{a.tasks + (b * nn + T) * kNodeTaskDoubles};
-                const double c = node_eval<false>(*a.model, ws + L.xs_try + (long)T * kNX, nullptr, tk, state_w, x_reg, ctrl_w, 0.0,
-                                                  true, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-                s.bc[0] = c; s.bc[1] = !(fabs(c) < INFINITY) ? 1.0 : 0.0;
-            }
-            __syncthreads();
+            if (lane == 0 && !terminal) { UNROLL_RBD for (int i = 0; i < kNX; ++i) s.x[i] = xn[i]; }
             cost_try += s.bc[0];
             failed = s.bc[1] != 0.0;
             __syncthreads();
@@ -567,22 +553,24 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
 __global__ void ik_centroidal_state_kernel(const RobotModelDev *model, const double *x, double *out9, int B) {
     const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    Kin k;
-    kin_compute<true>(*model, x + b * kNX, k);
+    Pass1 p1;
+    const int fid[kFrameSlots] = {-1, -1, -1, -1};
+    quad_pass1<false>(*model, x + b * kNX, fid, p1);
     for (int c = 0; c < 3; ++c) {
-        out9[b * 9 + c] = k.com[c];
-        out9[b * 9 + 3 + c] = k.hg[c] / k.M;     // vcom
-        out9[b * 9 + 6 + c] = k.hg[3 + c];       // hg.angular
+        out9[b * 9 + c] = p1.com[c];
+        out9[b * 9 + 3 + c] = p1.hg[c] / p1.M;     // vcom
+        out9[b * 9 + 6 + c] = p1.hg[3 + c];        // hg.angular
     }
 }
 
 __global__ void ik_com_mom_kernel(const RobotModelDev *model, const double *xs, double *com, double *mom, int n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Kin k;
-    kin_compute<true>(*model, xs + i * kNX, k);
-    for (int c = 0; c < 3; ++c) com[i * 3 + c] = k.com[c];
-    for (int c = 0; c < 6; ++c) mom[i * 6 + c] = k.hg[c];
+    Pass1 p1;
+    const int fid[kFrameSlots] = {-1, -1, -1, -1};
+    quad_pass1<false>(*model, xs + i * kNX, fid, p1);
+    for (int c = 0; c < 3; ++c) com[i * 3 + c] = p1.com[c];
+    for (int c = 0; c < 6; ++c) mom[i * 6 + c] = p1.hg[c];
 }
 
 // com / momentum references of the IK tracking tasks from the centroidal solution X
@@ -608,14 +596,13 @@ hipError_t ik_launch_fill_refs(double *tasks, const double *X, double m, int B, 
     hipLaunchKernelGGL(kd_fill_refs_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, tasks, X, m, B, H, T);
     return hipGetLastError();
 }
-
 hipError_t ik_launch_init(const IkBatchArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(ik_init_kernel, dim3((a.B + 63) / 64), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 hipError_t ik_launch_calcdiff(const IkBatchArgs &a, hipStream_t st) {
     const long n = (long)a.B * (a.T + 1);
-    hipLaunchKernelGGL(ik_calcdiff_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(ik_calcdiff_kernel, dim3((unsigned)n), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 hipError_t ik_launch_backward(const IkBatchArgs &a, hipStream_t st) {

@@ -20,6 +20,7 @@ struct RobotModelDev {
     int nj, nframes;
     int parent[kMaxJoints];          // -1 = base, else joint index
     int chain_end[kMaxJoints];       // last joint of the serial chain joint i belongs to
+    int R_identity[kMaxJoints];      // joint placement rotation is the identity (URDF rpy = 0)
     double R[kMaxJoints][9], p[kMaxJoints][3], axis[kMaxJoints][3];
     double mass[kMaxJoints + 1], com[kMaxJoints + 1][3], inertia[kMaxJoints + 1][6];  // xx xy xz yy yz zz
     int frame_body[kMaxFrames];

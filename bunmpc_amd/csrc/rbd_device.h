@@ -191,8 +191,8 @@ RBD_D void state_integrate(const double *x, const double *dx, double *xn) {
                    q[3] * d[3] - q[0] * d[0] - q[1] * d[1] - q[2] * d[2]};
     const double nr = 1.0 / sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
     for (int i = 0; i < 4; ++i) xn[3 + i] = r[i] * nr;
-    for (int i = 0; i < kNV - 6; ++i) xn[7 + i] = x[7 + i] + dx[6 + i];
-    for (int i = 0; i < kNV; ++i) xn[kNQ + i] = x[kNQ + i] + dx[kNV + i];
+    _Pragma("unroll") for (int i = 0; i < kNV - 6; ++i) xn[7 + i] = x[7 + i] + dx[6 + i];
+    _Pragma("unroll") for (int i = 0; i < kNV; ++i) xn[kNQ + i] = x[kNQ + i] + dx[kNV + i];
 }
 // d = x1 (-) x0 (36); optionally the 6x6 Jlog6 of the base block (d diff / d x1)
 template <bool JAC>
@@ -204,8 +204,8 @@ RBD_D void state_diff(const double *x0, const double *x1, double *d, double *Jl)
     dp[0] = x1[0] - x0[0]; dp[1] = x1[1] - x0[1]; dp[2] = x1[2] - x0[2];
     mat3Tvec(R0, dp, pr);
     log6(Rr, pr, d);
-    for (int i = 0; i < kNV - 6; ++i) d[6 + i] = x1[7 + i] - x0[7 + i];
-    for (int i = 0; i < kNV; ++i) d[kNV + i] = x1[kNQ + i] - x0[kNQ + i];
+    _Pragma("unroll") for (int i = 0; i < kNV - 6; ++i) d[6 + i] = x1[7 + i] - x0[7 + i];
+    _Pragma("unroll") for (int i = 0; i < kNV; ++i) d[kNV + i] = x1[kNQ + i] - x0[kNQ + i];
     if (JAC) jlog6(Rr, pr, Jl);
 }
 

@@ -1,0 +1,214 @@
+// Register-resident rigid-body passes for the "free-flyer + 4 legs x 3 revolute joints" topology
+// (Solo12, Go2): every loop has a compile-time trip count and every local array a compile-time
+// index, so nothing lives in scratch.  Same quantities and conventions as rbd_device.h /
+// oracle/rbd_np.py (which pin them by finite differences); used by the IK-DDP kernels.
+//   pass 1  (quad_pass1)   whole robot: CoM, momentum about the origin, centroidal momentum, the
+//                          whole-body composite inertia, positions of up to 4 task frames
+//   pass 2  (quad_column)  one velocity column: motion subspace S, CoM-Jacobian column, A_g column,
+//                          dh_g/dq column (d h_O/dq = S x* h_sub - I_sub (S x V_parent))
+#pragma once
+#include "rbd_device.h"
+
+#define UNROLL_RBD _Pragma("unroll")
+
+namespace bunmpc {
+namespace rbd {
+
+constexpr int kLegs = 4, kLegJoints = 3;
+
+struct BodyAcc { Comp c; double h[6]; };   // composite about the world origin + momentum
+
+RBD_D void rodrigues(const double *a, double q, double *R) {   // unit axis: R = c I + s [a]x + (1 - c) a a^T
+    const double s = sin(q), c = cos(q), c1 = 1.0 - c;
+    R[0] = c + c1 * a[0] * a[0]; R[1] = c1 * a[0] * a[1] - s * a[2]; R[2] = c1 * a[0] * a[2] + s * a[1];
+    R[3] = c1 * a[1] * a[0] + s * a[2]; R[4] = c + c1 * a[1] * a[1]; R[5] = c1 * a[1] * a[2] - s * a[0];
+    R[6] = c1 * a[2] * a[0] - s * a[1]; R[7] = c1 * a[2] * a[1] + s * a[0]; R[8] = c + c1 * a[2] * a[2];
+}
+
+// momentum (l, n_O) only -- no composite inertia: what a cost evaluation needs
+RBD_D void body_momentum(const RobotModelDev &m, int b, const double *R, const double *p, const double *V, double &mass,
+                         double *h1, double *h) {
+    double cw[3], t[3], wl[3], Iw[3], n[3];
+    mat3vec(R, m.com[b], cw);
+    UNROLL_RBD for (int c = 0; c < 3; ++c) cw[c] += p[c];
+    const double mb = m.mass[b];
+    cross3(V + 3, cw, t);
+    double l[3];
+    UNROLL_RBD for (int c = 0; c < 3; ++c) l[c] = mb * (V[c] + t[c]);
+    mat3Tvec(R, V + 3, wl);                               // angular velocity in the body frame
+    const double *I = m.inertia[b];
+    Iw[0] = I[0] * wl[0] + I[1] * wl[1] + I[2] * wl[2];
+    Iw[1] = I[1] * wl[0] + I[3] * wl[1] + I[4] * wl[2];
+    Iw[2] = I[2] * wl[0] + I[4] * wl[1] + I[5] * wl[2];
+    mat3vec(R, Iw, n);
+    cross3(cw, l, t);
+    mass += mb;
+    UNROLL_RBD for (int c = 0; c < 3; ++c) { h1[c] += mb * cw[c]; h[c] += l[c]; h[3 + c] += n[c] + t[c]; }
+}
+
+// composite (about the world origin) and momentum of body b placed at (R, p) moving with twist V
+template <bool VEL>
+RBD_D void body_terms(const RobotModelDev &m, int b, const double *R, const double *p, const double *V, BodyAcc &o) {
+    double cw[3], RI[9], Iw[9];
+    mat3vec(R, m.com[b], cw);
+    UNROLL_RBD for (int c = 0; c < 3; ++c) cw[c] += p[c];
+    const double I[9] = {m.inertia[b][0], m.inertia[b][1], m.inertia[b][2], m.inertia[b][1], m.inertia[b][3], m.inertia[b][4],
+                         m.inertia[b][2], m.inertia[b][4], m.inertia[b][5]};
+    mat3mul(R, I, RI);
+    UNROLL_RBD for (int i = 0; i < 3; ++i)
+        UNROLL_RBD for (int j = 0; j < 3; ++j)
+            Iw[3 * i + j] = RI[3 * i] * R[3 * j] + RI[3 * i + 1] * R[3 * j + 1] + RI[3 * i + 2] * R[3 * j + 2];
+    const double mb = m.mass[b], cc = dot3(cw, cw);
+    o.c.m = mb;
+    UNROLL_RBD for (int c = 0; c < 3; ++c) o.c.h1[c] = mb * cw[c];
+    o.c.I[0] = Iw[0] + mb * (cc - cw[0] * cw[0]); o.c.I[1] = Iw[1] - mb * cw[0] * cw[1]; o.c.I[2] = Iw[2] - mb * cw[0] * cw[2];
+    o.c.I[3] = Iw[4] + mb * (cc - cw[1] * cw[1]); o.c.I[4] = Iw[5] - mb * cw[1] * cw[2]; o.c.I[5] = Iw[8] + mb * (cc - cw[2] * cw[2]);
+    if (VEL) comp_apply(o.c, V, o.h);
+}
+
+// one joint of a chain: child placement, motion subspace column, child twist
+RBD_D void joint_step(const RobotModelDev &m, int i, double qi, double vi, const double *Rp, const double *pp, const double *Vp,
+                      double *R, double *p, double *S, double *V) {
+    double Rq[9], t[3];
+    rodrigues(m.axis[i], qi, Rq);
+    if (m.R_identity[i]) mat3mul(Rp, Rq, R);      // URDF joint origins with rpy = 0 (all of Solo12 / Go2)
+    else { double Rl[9]; mat3mul(m.R[i], Rq, Rl); mat3mul(Rp, Rl, R); }
+    mat3vec(Rp, m.p[i], t);
+    UNROLL_RBD for (int c = 0; c < 3; ++c) p[c] = t[c] + pp[c];
+    mat3vec(R, m.axis[i], S + 3);
+    cross3(p, S + 3, S);
+    UNROLL_RBD for (int c = 0; c < 6; ++c) V[c] = Vp[c] + S[c] * vi;
+}
+
+struct Pass1 {
+    double Rb[9], pb[3], Vb[6];
+    Comp call;                 // whole-robot composite about the origin
+    double hO[6], com[3], hg[6], M;
+    double fx[kFrameSlots][3]; // task-frame positions
+};
+
+// fid[s] < 0: slot unused.  COMPOSITE = false skips the whole-body composite inertia (cost-only passes).
+template <bool COMPOSITE>
+RBD_D void quad_pass1(const RobotModelDev &m, const double *x, const int *fid, Pass1 &o) {
+    quat_to_R(x + 3, o.Rb);
+    o.pb[0] = x[0]; o.pb[1] = x[1]; o.pb[2] = x[2];
+    const double *v = x + kNQ;
+    {   // base twist about the world origin: v_O = R v_lin + p x (R w)
+        double wl[3], vl[3], t[3];
+        mat3vec(o.Rb, v + 3, wl); mat3vec(o.Rb, v, vl); cross3(o.pb, wl, t);
+        UNROLL_RBD for (int c = 0; c < 3; ++c) { o.Vb[c] = vl[c] + t[c]; o.Vb[3 + c] = wl[c]; }
+    }
+    int fbody[kFrameSlots];
+    UNROLL_RBD for (int s = 0; s < kFrameSlots; ++s) {
+        fbody[s] = fid[s] >= 0 ? m.frame_body[fid[s]] : -1;
+        o.fx[s][0] = o.fx[s][1] = o.fx[s][2] = 0.0;
+    }
+    auto frames_on = [&](int b, const double *R, const double *p) {
+        UNROLL_RBD for (int s = 0; s < kFrameSlots; ++s)
+            if (fbody[s] == b) {
+                double t[3];
+                mat3vec(R, m.frame_p[fid[s]], t);
+                UNROLL_RBD for (int c = 0; c < 3; ++c) o.fx[s][c] = t[c] + p[c];
+            }
+    };
+    BodyAcc ba;
+    double h1[3] = {0, 0, 0};
+    o.M = 0.0;
+    UNROLL_RBD for (int c = 0; c < 6; ++c) o.hO[c] = 0.0;
+    if (COMPOSITE) {
+        body_terms<true>(m, 0, o.Rb, o.pb, o.Vb, ba);
+        o.call = ba.c;
+        UNROLL_RBD for (int c = 0; c < 6; ++c) o.hO[c] = ba.h[c];
+    } else body_momentum(m, 0, o.Rb, o.pb, o.Vb, o.M, h1, o.hO);
+    frames_on(0, o.Rb, o.pb);
+    UNROLL_RBD for (int L = 0; L < kLegs; ++L) {
+        double Rp[9], pp[3], Vp[6];
+        UNROLL_RBD for (int c = 0; c < 9; ++c) Rp[c] = o.Rb[c];
+        UNROLL_RBD for (int c = 0; c < 3; ++c) pp[c] = o.pb[c];
+        UNROLL_RBD for (int c = 0; c < 6; ++c) Vp[c] = o.Vb[c];
+        UNROLL_RBD for (int j = 0; j < kLegJoints; ++j) {
+            const int i = kLegJoints * L + j;
+            double R[9], p[3], S[6], V[6];
+            joint_step(m, i, x[7 + i], v[6 + i], Rp, pp, Vp, R, p, S, V);
+            if (COMPOSITE) {
+                body_terms<true>(m, i + 1, R, p, V, ba);
+                comp_add(o.call, ba.c);
+                UNROLL_RBD for (int c = 0; c < 6; ++c) o.hO[c] += ba.h[c];
+            } else body_momentum(m, i + 1, R, p, V, o.M, h1, o.hO);
+            frames_on(i + 1, R, p);
+            UNROLL_RBD for (int c = 0; c < 9; ++c) Rp[c] = R[c];
+            UNROLL_RBD for (int c = 0; c < 3; ++c) pp[c] = p[c];
+            UNROLL_RBD for (int c = 0; c < 6; ++c) Vp[c] = V[c];
+        }
+    }
+    if (COMPOSITE) { o.M = o.call.m; UNROLL_RBD for (int c = 0; c < 3; ++c) h1[c] = o.call.h1[c]; }
+    UNROLL_RBD for (int c = 0; c < 3; ++c) o.com[c] = h1[c] / o.M;
+    double t[3];
+    cross3(o.com, o.hO, t);
+    UNROLL_RBD for (int c = 0; c < 3; ++c) { o.hg[c] = o.hO[c]; o.hg[3 + c] = o.hO[3 + c] - t[c]; }
+}
+
+struct Column { double S[6], jc[3], ag[6], dh[6]; };
+
+// velocity column `col` (0..17) at state x; p1 = pass 1 of the same state
+RBD_D void quad_column(const RobotModelDev &m, const double *x, const Pass1 &p1, int col, Column &o) {
+    Comp cs; double hs[6], Vpar[6];
+    if (col < 6) {
+        const int a = col % 3;
+        const double e[3] = {p1.Rb[a], p1.Rb[3 + a], p1.Rb[6 + a]};
+        if (col < 3) { UNROLL_RBD for (int c = 0; c < 3; ++c) { o.S[c] = e[c]; o.S[3 + c] = 0.0; } }
+        else { cross3(p1.pb, e, o.S); UNROLL_RBD for (int c = 0; c < 3; ++c) o.S[3 + c] = e[c]; }
+        cs = p1.call;
+        UNROLL_RBD for (int c = 0; c < 6; ++c) { hs[c] = p1.hO[c]; Vpar[c] = 0.0; }
+    } else {
+        const int L = (col - 6) / kLegJoints, jsel = (col - 6) % kLegJoints;
+        const double *v = x + kNQ;
+        double Rp[9], pp[3], Vp[6];
+        UNROLL_RBD for (int c = 0; c < 9; ++c) Rp[c] = p1.Rb[c];
+        UNROLL_RBD for (int c = 0; c < 3; ++c) pp[c] = p1.pb[c];
+        UNROLL_RBD for (int c = 0; c < 6; ++c) Vp[c] = p1.Vb[c];
+        comp_zero(cs);
+        UNROLL_RBD for (int c = 0; c < 6; ++c) { hs[c] = 0.0; Vpar[c] = 0.0; o.S[c] = 0.0; }
+        UNROLL_RBD for (int j = 0; j < kLegJoints; ++j) {
+            const int i = kLegJoints * L + j;
+            double R[9], p[3], S[6], V[6];
+            joint_step(m, i, x[7 + i], v[6 + i], Rp, pp, Vp, R, p, S, V);
+            BodyAcc ba;
+            body_terms<true>(m, i + 1, R, p, V, ba);
+            if (j == jsel) { UNROLL_RBD for (int c = 0; c < 6; ++c) { o.S[c] = S[c]; Vpar[c] = Vp[c]; } }
+            if (j >= jsel) { comp_add(cs, ba.c); UNROLL_RBD for (int c = 0; c < 6; ++c) hs[c] += ba.h[c]; }   // subtree = joints jsel..2
+            UNROLL_RBD for (int c = 0; c < 9; ++c) Rp[c] = R[c];
+            UNROLL_RBD for (int c = 0; c < 3; ++c) pp[c] = p[c];
+            UNROLL_RBD for (int c = 0; c < 6; ++c) Vp[c] = V[c];
+        }
+    }
+    double h[6], t3[3], a3[3], b3[3];
+    comp_apply(cs, o.S, h);
+    UNROLL_RBD for (int c = 0; c < 3; ++c) o.jc[c] = h[c] / p1.M;
+    cross3(p1.com, h, t3);
+    UNROLL_RBD for (int c = 0; c < 3; ++c) { o.ag[c] = h[c]; o.ag[3 + c] = h[3 + c] - t3[c]; }
+    double cf[6], sxv[6], ih[6];
+    cross3(o.S + 3, hs, cf);
+    cross3(o.S + 3, hs + 3, a3); cross3(o.S, hs, b3);
+    UNROLL_RBD for (int c = 0; c < 3; ++c) cf[3 + c] = a3[c] + b3[c];
+    cross3(o.S + 3, Vpar, a3); cross3(o.S, Vpar + 3, b3);
+    UNROLL_RBD for (int c = 0; c < 3; ++c) sxv[c] = a3[c] + b3[c];
+    cross3(o.S + 3, Vpar + 3, sxv + 3);
+    comp_apply(cs, sxv, ih);
+    double dO[6];
+    UNROLL_RBD for (int c = 0; c < 6; ++c) dO[c] = cf[c] - ih[c];
+    cross3(o.jc, p1.hO, a3); cross3(p1.com, dO, b3);
+    UNROLL_RBD for (int c = 0; c < 3; ++c) { o.dh[c] = dO[c]; o.dh[3 + c] = dO[3 + c] - a3[c] - b3[c]; }
+}
+
+// does column col move the body that carries frame f?  (legs numbered 3L..3L+2, body = joint + 1)
+RBD_D bool quad_supports(const RobotModelDev &m, int f, int col) {
+    if (col < 6) return true;
+    const int b = m.frame_body[f];
+    if (b == 0) return false;
+    const int jf = b - 1, jc = col - 6;
+    return (jf / kLegJoints == jc / kLegJoints) && (jc <= jf);
+}
+
+}  // namespace rbd
+}  // namespace bunmpc
