@@ -140,10 +140,16 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
     const int maxit = a.c.maxit;
     const double rho2 = 2.0 * rho;
 
-    double *Xg = a.X + pb * nx + 9L * t;
-    double *Fg = a.F + pb * nf + (long)NF * t;
-    double *Pg = a.P + pb * nx + 9L * t;
-    double *PIg = a.P + pb * nx + 9L * H;
+    // Iterates at phase boundaries (X, F, P of this segment's problem) live in LDS, each lane touching
+    // only its own knot's blocks (lane 0 also the x_init rows of P): HBM sees the inputs once and the
+    // results once.  Layout after the momentum table: per segment [X nx | P nx | F nf].
+    double *seg_lds = cmtab + ((maxit + 1) & ~1) + (long)seg * (2 * nx + nf);
+    double *Xg = seg_lds + 9L * t;
+    double *Pg = seg_lds + nx + 9L * t;
+    double *PIg = seg_lds + nx + 9L * H;
+    double *Fg = seg_lds + 2 * nx + (long)NF * t;
+    double *Xout = a.X + pb * nx + 9L * t, *Fout = a.F + pb * nf + (long)NF * t, *Pout = a.P + pb * nx + 9L * t;
+    double *PIout = a.P + pb * nx + 9L * H;
 
     {   // momentum table: t+ = 1 + sqrt(1 + 4 t^2)/2 (sic, fista.cpp:34), c = (t - 1)/t+
         double tk = 1.0;
@@ -167,6 +173,13 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
             UNROLL for (int l = 0; l < 9; ++l) Pg[l] = 0.0;
         }
         if (l0) { UNROLL for (int l = 0; l < 9; ++l) PIg[l] = 0.0; }
+    } else {     // set_warm_start_vars: bring the caller's iterates on chip
+        if (kvalid) { UNROLL for (int l = 0; l < 9; ++l) Xg[l] = Xout[l]; }
+        if (rvalid) {
+            UNROLL for (int j = 0; j < NF; ++j) Fg[j] = Fout[j];
+            UNROLL for (int l = 0; l < 9; ++l) Pg[l] = Pout[l];
+        }
+        if (l0) { UNROLL for (int l = 0; l < 9; ++l) PIg[l] = PIout[l]; }
     }
     bool alive = pvalid;
     int n_admm = 0, it_f = 0, it_x = 0, bt_f = 0, bt_x = 0, status = 0;
@@ -512,7 +525,13 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
         }
     }
 
-    // ---- results (X, F, P are already in place)
+    // ---- results: one pass from LDS to the output blocks
+    if (kvalid) { UNROLL for (int l = 0; l < 9; ++l) Xout[l] = Xg[l]; }
+    if (rvalid) {
+        UNROLL for (int j = 0; j < NF; ++j) Fout[j] = Fg[j];
+        UNROLL for (int l = 0; l < 9; ++l) Pout[l] = Pg[l];
+    }
+    if (l0) { UNROLL for (int l = 0; l < 9; ++l) PIout[l] = PIg[l]; }
     if (l0) {
         a.L_x[pb] = L_x;
         a.L_f[pb] = L_f;
@@ -539,7 +558,8 @@ template <int LPP, bool RAW, bool HASQF>
 hipError_t launch(const BatchArgs &a, hipStream_t stream) {
     const int per_wave = 64 / LPP;
     const unsigned grid = (unsigned)((a.B + per_wave - 1) / per_wave);
-    const size_t lds = sizeof(double) * (size_t)(a.c.maxit > 0 ? a.c.maxit : 1);
+    const size_t nstate = 2 * 9 * (size_t)(a.H + 1) + 12 * (size_t)a.H;   // X, P, F of one problem
+    const size_t lds = sizeof(double) * ((((size_t)a.c.maxit + 1) & ~(size_t)1) + per_wave * nstate);
     hipLaunchKernelGGL((biconvex_admm_kernel<LPP, 4, RAW, HASQF>), dim3(grid), dim3(64), lds, stream, a);
     return hipGetLastError();
 }
