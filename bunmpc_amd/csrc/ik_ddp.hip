@@ -241,15 +241,17 @@ __global__ __launch_bounds__(64) void ik_calcdiff_kernel(const IkBatchArgs a) {
 // --------------------------------------------------------------------------- backward ---
 constexpr int LD = kNDX + 1;   // padded leading dimension of the 36-wide LDS matrices
 constexpr int LDU = kNV + 1;
+constexpr int kBwdThreads = 256;   // four waves share one problem's Riccati step
 
 struct BackwardLds {
     double V[kNDX * LD], M1[kNDX * LD], W[kNDX * LD];
     double Qxu[kNDX * LDU], VFu[kNDX * LDU], Kt[kNV * LD], Quu[kNV * LDU];
     double Vx[kNDX], Qx[kNDX], Qu[kNV], kf[kNV], fs[kNDX], A6[36], B6[36], Luu[kNV], tmp[kNDX];
+    double idg[kNV];
     int flag;
 };
 
-__global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
+__global__ __launch_bounds__(kBwdThreads) void ik_backward_kernel(const IkBatchArgs a) {
     __shared__ BackwardLds s;
     const long b = blockIdx.x;
     const int lane = threadIdx.x;
@@ -274,11 +276,15 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
                 state_diff<false>(xa, xb, d, nullptr);
                 UNROLL_RBD for (int i = 0; i < kNDX; ++i) { ws[L.fs + (long)lane * kNDX + i] = d[i]; mx = fmax(mx, fabs(d[i])); }
             }
-            const bool ok = __all(mx < 1e-16);   // th_gaptol_
-            feas = ok;
-            if (lane == 0) sc[S_FEAS] = ok ? 1.0 : 0.0;
+            if (lane == 0) s.flag = 0;
+            __syncthreads();
+            if (!(mx < 1e-16)) s.flag = 1;       // th_gaptol_
+            __syncthreads();
+            feas = s.flag == 0;
+            __syncthreads();
+            if (lane == 0) sc[S_FEAS] = feas ? 1.0 : 0.0;
         } else if (!wasfeas) {
-            for (long i = lane; i < (long)(T + 1) * kNDX; i += 64) ws[L.fs + i] = 0.0;
+            for (long i = lane; i < (long)(T + 1) * kNDX; i += kBwdThreads) ws[L.fs + i] = 0.0;
         } else {
             if (lane <= T) ws[L.fs + (long)lane * kNDX] = 0.0;   // the parked node costs
         }
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
     double xreg = sc[S_XREG];
     for (;;) {   // computeDirection with regularisation retries (solver-ddp.cpp solve())
         if (lane == 0) s.flag = 0;
-        for (int e = lane; e < kNDX * kNDX; e += 64) {
+        for (int e = lane; e < kNDX * kNDX; e += kBwdThreads) {
             const int i = e / kNDX, j = e % kNDX;
             s.V[i * LD + j] = ws[L.Lxx + (long)T * kNDX * kNDX + e] + (i == j ? xreg : 0.0);
         }
@@ -309,10 +315,10 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             if (lane < 36) { s.A6[lane] = ws[L.A6 + (long)t * 36 + lane]; s.B6[lane] = ws[L.B6 + (long)t * 36 + lane]; }
             if (lane < kNV) s.Luu[lane] = ws[L.Luu + (long)t * kNV + lane];
             if (lane < kNDX) s.fs[lane] = ws[L.fs + (long)t * kNDX + lane];
-            for (int e = lane; e < kNDX * kNDX; e += 64) s.W[(e / kNDX) * LD + e % kNDX] = ws[L.Lxx + (long)t * kNDX * kNDX + e];
+            for (int e = lane; e < kNDX * kNDX; e += kBwdThreads) s.W[(e / kNDX) * LD + e % kNDX] = ws[L.Lxx + (long)t * kNDX * kNDX + e];
             __syncthreads();
             // M1 = Fx^T V
-            for (int e = lane; e < kNDX * kNDX; e += 64) {
+            for (int e = lane; e < kNDX * kNDX; e += kBwdThreads) {
                 const int i = e / kNDX, j = e % kNDX;
                 double v;
                 if (i < 6) { v = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) v += s.A6[6 * c + i] * s.V[c * LD + j]; }
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             }
             __syncthreads();
             // W = Lxx + M1 Fx ; Qxu = M1 Fu ; VFu = V Fu
-            for (int e = lane; e < kNDX * kNDX; e += 64) {
+            for (int e = lane; e < kNDX * kNDX; e += kBwdThreads) {
                 const int i = e / kNDX, j = e % kNDX;
                 double v;
                 if (j < 6) { v = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) v += s.M1[i * LD + c] * s.A6[6 * c + j]; }
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
                 else v = dt * s.M1[i * LD + (j - kNV)] + s.M1[i * LD + j];
                 s.W[i * LD + j] += v;
             }
-            for (int e = lane; e < kNDX * kNV; e += 64) {
+            for (int e = lane; e < kNDX * kNV; e += kBwdThreads) {
                 const int i = e / kNV, q = e % kNV;
                 double v1, v2;
                 if (q < 6) {
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             }
             __syncthreads();
             // Quu = Luu + Fu^T (V Fu) + ureg I
-            for (int e = lane; e < kNV * kNV; e += 64) {
+            for (int e = lane; e < kNV * kNV; e += kBwdThreads) {
                 const int p = e / kNV, q = e % kNV;
                 double v;
                 if (p < 6) { v = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) v += s.B6[6 * c + p] * s.VFu[c * LDU + q]; } else v = s.VFu[p * LDU + q];
@@ -370,32 +376,37 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             }
             __syncthreads();
             // Cholesky (lower, in place); a non-positive or NaN pivot fails the pass (Eigen::LLT info != Success)
+            // (columns stay unscaled during the elimination -- one barrier per step -- and are divided by
+            //  sqrt(pivot) in a single pass afterwards)
             for (int j = 0; j < kNV; ++j) {
                 const double piv = s.Quu[j * LDU + j];
                 if (!(piv > 0.0)) { if (lane == 0) s.flag = 1; }
-                const double d = sqrt(piv);
-                __syncthreads();
-                if (lane == 0) s.Quu[j * LDU + j] = d;
-                if (lane > j && lane < kNV) s.Quu[lane * LDU + j] /= d;
-                __syncthreads();
-                for (int e = lane; e < kNV * kNV; e += 64) {
+                const double ip = 1.0 / piv;
+                for (int e = lane; e < kNV * kNV; e += kBwdThreads) {
                     const int p = e / kNV, q = e % kNV;
-                    if (q > j && p >= q) s.Quu[p * LDU + q] -= s.Quu[p * LDU + j] * s.Quu[q * LDU + j];
+                    if (q > j && p >= q) s.Quu[p * LDU + q] -= s.Quu[p * LDU + j] * s.Quu[q * LDU + j] * ip;
                 }
                 __syncthreads();
             }
+            for (int e = lane; e < kNV * kNV; e += kBwdThreads) {
+                const int p = e / kNV, q = e % kNV;
+                if (p > q) s.Quu[p * LDU + q] /= sqrt(s.Quu[q * LDU + q]);
+            }
+            __syncthreads();
+            if (lane < kNV) { const double d = sqrt(s.Quu[lane * LDU + lane]); s.Quu[lane * LDU + lane] = d; s.idg[lane] = 1.0 / d; }
+            __syncthreads();
             // K = Quu^-1 Qxu^T: lane j < 36 solves for column j (18 unknowns in registers); lane 36: k = Quu^-1 Qu
             if (lane <= kNDX) {
                 double y[kNV];
                 UNROLL_RBD for (int p = 0; p < kNV; ++p) {
                     double v = lane < kNDX ? s.Qxu[lane * LDU + p] : s.Qu[p];
                     UNROLL_RBD for (int q = 0; q < p; ++q) v -= s.Quu[p * LDU + q] * y[q];
-                    y[p] = v / s.Quu[p * LDU + p];
+                    y[p] = v * s.idg[p];
                 }
                 UNROLL_RBD for (int p = kNV - 1; p >= 0; --p) {
                     double v = y[p];
                     UNROLL_RBD for (int q = p + 1; q < kNV; ++q) v -= s.Quu[q * LDU + p] * y[q];
-                    y[p] = v / s.Quu[p * LDU + p];
+                    y[p] = v * s.idg[p];
                 }
                 if (lane < kNDX) { UNROLL_RBD for (int p = 0; p < kNV; ++p) s.Kt[p * LD + lane] = y[p]; }
                 else { UNROLL_RBD for (int p = 0; p < kNV; ++p) s.kf[p] = y[p]; }
@@ -411,10 +422,10 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
                 ws[L.kff + (long)t * kNV + lane] = s.kf[lane];
                 ws[L.Qu + (long)t * kNV + lane] = s.Qu[lane];
             }
-            for (int e = lane; e < kNV * kNDX; e += 64) ws[L.K + (long)t * kNV * kNDX + e] = s.Kt[(e / kNDX) * LD + e % kNDX];
+            for (int e = lane; e < kNV * kNDX; e += kBwdThreads) ws[L.K + (long)t * kNV * kNDX + e] = s.Kt[(e / kNDX) * LD + e % kNDX];
             // Vx = Qx - K^T Qu ; Vxx = Qxx - Qxu K (into M1), then symmetrise + xreg
             if (lane < kNDX) { double v = s.Qx[lane]; UNROLL_RBD for (int p = 0; p < kNV; ++p) v -= s.Kt[p * LD + lane] * s.Qu[p]; s.Vx[lane] = v; }
-            for (int e = lane; e < kNDX * kNDX; e += 64) {
+            for (int e = lane; e < kNDX * kNDX; e += kBwdThreads) {
                 const int i = e / kNDX, j = e % kNDX;
                 double v = s.W[i * LD + j];
                 UNROLL_RBD for (int p = 0; p < kNV; ++p) v -= s.Qxu[i * LDU + p] * s.Kt[p * LD + j];
@@ -422,7 +433,7 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             }
             __syncthreads();
             bool bad = false;
-            for (int e = lane; e < kNDX * kNDX; e += 64) {
+            for (int e = lane; e < kNDX * kNDX; e += kBwdThreads) {
                 const int i = e / kNDX, j = e % kNDX;
                 const double v = 0.5 * (s.M1[i * LD + j] + s.M1[j * LD + i]) + (i == j ? xreg : 0.0);
                 s.V[i * LD + j] = v;
@@ -433,7 +444,7 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             __syncthreads();
             if (!feas && lane < kNDX) s.Vx[lane] = s.tmp[lane];
             if (lane < kNDX) bad = bad || !(fabs(s.Vx[lane]) < INFINITY);   // raiseIfNaN on Vx / Vxx
-            if (__any(bad) && lane == 0) s.flag = 1;
+            if (bad) s.flag = 1;
             __syncthreads();
             if (s.flag) break;
         }
@@ -450,6 +461,8 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
     }
     // expectedImprovement / stoppingCriteria ingredients
     double d1 = 0.0, d2 = 0.0, st = 0.0;
+    __syncthreads();
+    if (lane >= 64) return;
     for (int e = lane; e < T * kNV; e += 64) {
         const double qu = ws[L.Qu + e], kk = ws[L.kff + e];
         d1 += qu * kk; d2 -= kk * ws[L.Quuk + e]; st += qu * qu;
@@ -459,7 +472,7 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
 }
 
 // ---------------------------------------------------------------------------- forward ---
-struct ForwardLds { RobotModelDev m; double dx[kNDX], u[kNV], x[kNX]; double bc[4]; };
+struct ForwardLds { RobotModelDev m; double dx[kNDX], u[kNV], x[kNX], xn[kNX]; double part[kLegs + 1][10 + 3 * kFrameSlots]; double bc[4]; };
 
 __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
     __shared__ ForwardLds s;
@@ -503,18 +516,74 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
                 }
                 __syncthreads();
             }
-            double xn[kNX];
-            if (lane == 0) {
-                NodeTasks tk{a.tasks + (b * nn + t) * kNodeTaskDoubles};
-                const double c = node_cost(m, s.x, s.u, tk, state_w, x_reg, ctrl_w, terminal ? 0.0 : a.dt[b * T + t], terminal, xn);
-                bool bad = !(fabs(c) < INFINITY);
-                if (!terminal) {
-                    UNROLL_RBD for (int i = 0; i < kNX; ++i) { ws[L.xs_try + (long)(t + 1) * kNX + i] = xn[i]; bad = bad || !(fabs(xn[i]) < INFINITY); }
+            // node evaluation spread over lanes: 0..3 legs, 4 base body, 5 state residual, 6 control cost + Euler step
+            NodeTasks tk{a.tasks + (b * nn + t) * kNodeTaskDoubles};
+            const double dtn = terminal ? 0.0 : a.dt[b * T + t];
+            if (lane <= kLegs) {
+                int fid[kFrameSlots];
+                UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) fid[f] = tk.frame_w(f) != 0.0 ? tk.frame_id(f) : -1;
+                PartSum ps;
+                quad_part(m, s.x, fid, lane, ps);
+                s.part[lane][0] = ps.mass;
+                UNROLL_RBD for (int c = 0; c < 3; ++c) s.part[lane][1 + c] = ps.h1[c];
+                UNROLL_RBD for (int c = 0; c < 6; ++c) s.part[lane][4 + c] = ps.hO[c];
+                UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
+                    UNROLL_RBD for (int c = 0; c < 3; ++c) s.part[lane][10 + 3 * f + c] = ps.fhit[f] ? ps.fx[f][c] : 0.0;
+            } else if (lane == 5) {
+                double acc = 0.0;
+                if (tk.state_w() != 0.0) {
+                    double rs[kNDX];
+                    state_diff<false>(x_reg, s.x, rs, nullptr);
+                    UNROLL_RBD for (int i = 0; i < kNDX; ++i) acc += state_w[i] * rs[i] * rs[i];
                 }
-                s.bc[0] = c; s.bc[1] = bad ? 1.0 : 0.0;
+                s.bc[2] = tk.state_w() * 0.5 * acc;
+            } else if (lane == 6) {
+                double acc = 0.0;
+                if (!terminal) {
+                    UNROLL_RBD for (int i = 0; i < kNV; ++i) acc += ctrl_w[i] * s.u[i] * s.u[i];
+                    double xn[kNX];
+                    euler_step<false>(s.x, s.u, dtn, xn, nullptr, nullptr);
+                    bool bad = false;
+                    UNROLL_RBD for (int i = 0; i < kNX; ++i) { ws[L.xs_try + (long)(t + 1) * kNX + i] = xn[i]; s.xn[i] = xn[i]; bad = bad || !(fabs(xn[i]) < INFINITY); }
+                    s.bc[1] = bad ? 1.0 : 0.0;
+                } else s.bc[1] = 0.0;
+                s.bc[3] = tk.ctrl_w() * 0.5 * acc;
             }
             __syncthreads();
-            if (lane == 0 && !terminal) { UNROLL_RBD for (int i = 0; i < kNX; ++i) s.x[i] = xn[i]; }
+            if (lane == 0) {   // add the parts: CoM, centroidal momentum, residual costs
+                double M = 0.0, h1[3] = {0, 0, 0}, hO[6] = {0, 0, 0, 0, 0, 0}, fx[kFrameSlots][3];
+                UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) fx[f][0] = fx[f][1] = fx[f][2] = 0.0;
+                UNROLL_RBD for (int pa = 0; pa <= kLegs; ++pa) {
+                    M += s.part[pa][0];
+                    UNROLL_RBD for (int c = 0; c < 3; ++c) h1[c] += s.part[pa][1 + c];
+                    UNROLL_RBD for (int c = 0; c < 6; ++c) hO[c] += s.part[pa][4 + c];
+                    UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
+                        UNROLL_RBD for (int c = 0; c < 3; ++c) fx[f][c] += s.part[pa][10 + 3 * f + c];
+                }
+                double com[3], t3[3], c = 0.0, acc = 0.0;
+                UNROLL_RBD for (int k = 0; k < 3; ++k) com[k] = h1[k] / M;
+                cross3(com, hO, t3);
+                UNROLL_RBD for (int k = 0; k < 3; ++k) {
+                    const double rl = hO[k] - tk.mom_ref()[k], ra = hO[3 + k] - t3[k] - tk.mom_ref()[3 + k];
+                    acc += rl * rl + ra * ra;
+                }
+                c += tk.mom_w() * 0.5 * acc;
+                acc = 0.0;
+                UNROLL_RBD for (int k = 0; k < 3; ++k) { const double r = com[k] - tk.com_ref()[k]; acc += r * r; }
+                c += tk.com_w() * 0.5 * acc;
+                UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) {
+                    const double w = tk.frame_w(f);
+                    acc = 0.0;
+                    UNROLL_RBD for (int k = 0; k < 3; ++k) { const double r = w != 0.0 ? fx[f][k] - tk.frame_ref(f)[k] : 0.0; acc += r * r; }
+                    c += w * 0.5 * acc;
+                }
+                c += s.bc[2] + s.bc[3];
+                if (!terminal) c *= dtn;
+                if (!(fabs(c) < INFINITY)) s.bc[1] = 1.0;
+                s.bc[0] = c;
+            }
+            __syncthreads();
+            if (lane < kNX && !terminal) s.x[lane] = s.xn[lane];
             cost_try += s.bc[0];
             failed = s.bc[1] != 0.0;
             __syncthreads();
@@ -606,7 +675,7 @@ hipError_t ik_launch_calcdiff(const IkBatchArgs &a, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t ik_launch_backward(const IkBatchArgs &a, hipStream_t st) {
-    hipLaunchKernelGGL(ik_backward_kernel, dim3(a.B), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(ik_backward_kernel, dim3(a.B), dim3(kBwdThreads), 0, st, a);
     return hipGetLastError();
 }
 hipError_t ik_launch_forward(const IkBatchArgs &a, hipStream_t st) {

@@ -148,6 +148,60 @@ RBD_D void quad_pass1(const RobotModelDev &m, const double *x, const int *fid, P
     UNROLL_RBD for (int c = 0; c < 3; ++c) { o.hg[c] = o.hO[c]; o.hg[3 + c] = o.hO[3 + c] - t[c]; }
 }
 
+// Partial sums of one part of the robot (part 0..3 = leg, part 4 = base body): mass, first moment,
+// momentum about the origin, and the position of task frames carried by that part.  Lets a wave
+// spread one node evaluation over five lanes (forward rollout) and add the parts in LDS.
+struct PartSum { double mass, h1[3], hO[6], fx[kFrameSlots][3]; int fhit[kFrameSlots]; };
+
+RBD_D void quad_part(const RobotModelDev &m, const double *x, const int *fid, int part, PartSum &o) {
+    double Rb[9], pb[3], Vb[6];
+    quat_to_R(x + 3, Rb);
+    pb[0] = x[0]; pb[1] = x[1]; pb[2] = x[2];
+    const double *v = x + kNQ;
+    {
+        double wl[3], vl[3], t[3];
+        mat3vec(Rb, v + 3, wl); mat3vec(Rb, v, vl); cross3(pb, wl, t);
+        UNROLL_RBD for (int c = 0; c < 3; ++c) { Vb[c] = vl[c] + t[c]; Vb[3 + c] = wl[c]; }
+    }
+    o.mass = 0.0;
+    UNROLL_RBD for (int c = 0; c < 3; ++c) o.h1[c] = 0.0;
+    UNROLL_RBD for (int c = 0; c < 6; ++c) o.hO[c] = 0.0;
+    int fbody[kFrameSlots];
+    UNROLL_RBD for (int s = 0; s < kFrameSlots; ++s) {
+        fbody[s] = fid[s] >= 0 ? m.frame_body[fid[s]] : -1;
+        o.fhit[s] = 0;
+        o.fx[s][0] = o.fx[s][1] = o.fx[s][2] = 0.0;
+    }
+    auto frames_on = [&](int b, const double *R, const double *p) {
+        UNROLL_RBD for (int s = 0; s < kFrameSlots; ++s)
+            if (fbody[s] == b) {
+                double t[3];
+                mat3vec(R, m.frame_p[fid[s]], t);
+                UNROLL_RBD for (int c = 0; c < 3; ++c) o.fx[s][c] = t[c] + p[c];
+                o.fhit[s] = 1;
+            }
+    };
+    if (part == kLegs) {
+        body_momentum(m, 0, Rb, pb, Vb, o.mass, o.h1, o.hO);
+        frames_on(0, Rb, pb);
+        return;
+    }
+    double Rp[9], pp[3], Vp[6];
+    UNROLL_RBD for (int c = 0; c < 9; ++c) Rp[c] = Rb[c];
+    UNROLL_RBD for (int c = 0; c < 3; ++c) pp[c] = pb[c];
+    UNROLL_RBD for (int c = 0; c < 6; ++c) Vp[c] = Vb[c];
+    UNROLL_RBD for (int j = 0; j < kLegJoints; ++j) {
+        const int i = kLegJoints * part + j;      // runtime leg: model / state reads are indexed, locals are not
+        double R[9], p[3], S[6], V[6];
+        joint_step(m, i, x[7 + i], v[6 + i], Rp, pp, Vp, R, p, S, V);
+        body_momentum(m, i + 1, R, p, V, o.mass, o.h1, o.hO);
+        frames_on(i + 1, R, p);
+        UNROLL_RBD for (int c = 0; c < 9; ++c) Rp[c] = R[c];
+        UNROLL_RBD for (int c = 0; c < 3; ++c) pp[c] = p[c];
+        UNROLL_RBD for (int c = 0; c < 6; ++c) Vp[c] = V[c];
+    }
+}
+
 struct Column { double S[6], jc[3], ag[6], dh[6]; };
 
 // velocity column `col` (0..17) at state x; p1 = pass 1 of the same state
