@@ -106,7 +106,8 @@ def gait_percent_in_phase(t, period, stance_percent, offset):
     """gait_planner.cpp:112-128."""
     st = period * stance_percent
     phi = gait_phi(t, period, offset)
-    return np.where(phi <= st, phi / st, (phi - st) / (period - st))
+    with np.errstate(divide="ignore", invalid="ignore"):     # 100 % stance: the swing branch is never selected
+        return np.where(phi <= st, phi / st, (phi - st) / (period - st))
 
 
 # ------------------------------------------------------------- contact plan ---
@@ -322,6 +323,24 @@ def make_batch(config, B, first=0, seed=None, H=None):
 SOLO12_Q0 = np.array([0, 0, 0.2409, 0, 0, 0, 1] + [0, 0.8, -1.6] * 2 + [0, -0.8, 1.6] * 2, float)  # feet at z = foot_size
 FEET = ("FL_FOOT", "FR_FOOT", "HL_FOOT", "HR_FOOT")     # abstract_cyclic_gen.py:37
 HIPS = ("FL_HFE", "FR_HFE", "HL_HFE", "HR_HFE")         # abstract_cyclic_gen.py:38
+
+
+@dataclass
+class WholeBodyRobot:
+    """What the harness constructor reads from a robot_properties config (abstract_cyclic_gen.py:28-76)"""
+    name: str
+    q0: np.ndarray             # nominal configuration (feet on the ground)
+    feet: tuple                # eff_names
+    hips: tuple                # hip_names
+    mu: float = 1.0            # friction coefficient of the force projection (fista.hpp:49: 1.0 in the reference)
+
+
+SOLO12_WB = WholeBodyRobot("solo12", SOLO12_Q0, FEET, HIPS)
+# synthetic (SURVEY 8d config 5): robot_properties_go2/config.py:108-113,162-165 names / joint angles,
+# base lowered from 0.35 so the feet rest at z = foot radius 0.02
+GO2_Q0 = np.array([0, 0, 0.3168, 0, 0, 0, 1] + [0, 0.8, -1.6] * 4, float)
+GO2_WB = WholeBodyRobot("go2", GO2_Q0, ("FL_foot", "FR_foot", "RL_foot", "RR_foot"),
+                        ("FL_thigh_joint", "FR_thigh_joint", "RL_thigh_joint", "RR_thigh_joint"), mu=10.0)
 # IK weights of the trot plan (motions/cyclic/solo12_trot.py:22-31)
 TROT_IK = dict(state_wt=np.array([0., 0, 10] + [1000] * 3 + [1.0] * 12 + [0.] * 3 + [100] * 3 + [0.5] * 12),
                ctrl_wt=np.array([0, 0, 1000] + [5e2] * 3 + [1.0] * 12), swing_wt=(1e4, 1e4), cent_wt=(0.0, 5e2),
@@ -350,11 +369,13 @@ def _log3_batch(R):
     return f[:, None] * v
 
 
-def make_wb_batch(model, B, first=0, seed=None, gait=TROT, ik=TROT_IK, ik_hor_ratio=0.5):
+def make_wb_batch(model, B, first=0, seed=None, gait=TROT, ik=TROT_IK, ik_hor_ratio=0.5, wb=None):
     """Perturbed whole-body states and everything SoloMpcGaitGen.optimize hands to KinoDynMP
     (abstract_cyclic_gen.py:629-663): contact plan from the feet / CoM of (q, v), centroidal costs
     (create_costs :564-614) and the IK task list (:545-562).  Solo12 trot by default."""
     from . import fk_np
+    wb = SOLO12_WB if wb is None else wb
+    Q0, FEET, HIPS = wb.q0, wb.feet, wb.hips
     seed = BASE_SEED + 5 if seed is None else seed
     H = gait.horizon
     T = int(np.round(ik_hor_ratio * gait.gait_horizon * gait.gait_period / gait.gait_dt, 2))   # :128
@@ -365,7 +386,7 @@ def make_wb_batch(model, B, first=0, seed=None, gait=TROT, ik=TROT_IK, ik_hor_ra
     dq[:, 2] = 0.01 * nrm[:, 0]
     dq[:, 3:6] = 0.05 * nrm[:, 1:4]
     dq[:, 6:] = 0.05 * nrm[:, 4:16]
-    q = np.tile(SOLO12_Q0, (B, 1))
+    q = np.tile(Q0, (B, 1))
     q[:, 2] += dq[:, 2]
     # small rotation: quaternion of exp(w)
     w = dq[:, 3:6]
@@ -382,7 +403,7 @@ def make_wb_batch(model, B, first=0, seed=None, gait=TROT, ik=TROT_IK, ik_hor_ra
     Rb = kin["oR"][0]
     v_des = np.einsum("bij,bj->bi", Rb, v_des_b)                    # :642-643
     # constructor offsets from the nominal configuration (:41-76)
-    k0 = fk_np.kinematics(model, SOLO12_Q0[None])
+    k0 = fk_np.kinematics(model, Q0[None])
     offs = np.round(fk_np.frame_positions(model, k0, HIPS)[0] - k0["com"][0], 3)
     offs[:, 1] += np.array([0.04, -0.04, 0.04, -0.04])
     yaw = np.arctan2(Rb[:, 1, 0], Rb[:, 0, 0])
@@ -391,15 +412,16 @@ def make_wb_batch(model, B, first=0, seed=None, gait=TROT, ik=TROT_IK, ik_hor_ra
                         sy[:, None] * offs[None, :, 0] + cy[:, None] * offs[None, :, 1]], axis=2)   # (B,4,2)
     feet0 = np.round(fk_np.frame_positions(model, kin, FEET), 3)
     com_xy = np.round(kin["com"][:, 0:2], 3)
-    robot = RobotParams("solo12", model.total_mass, SOLO12.feet_xy, offs[:, 0:2], float(k0["com"][0, 2]))
+    robot = RobotParams(wb.name, model.total_mass, fk_np.frame_positions(model, k0, FEET)[0][:, 0:2], offs[:, 0:2],
+                        float(k0["com"][0, 2]))
     cnt, swing, dt = contact_plan(gait, robot, H, t0, com_xy, kin["com"][:, 2], feet0, v_des, np.zeros(B), hip_off)
     x_init = np.concatenate([kin["com"], kin["vcom"], kin["L"]], axis=1)
     amom = _log3_batch(np.transpose(Rb, (0, 2, 1)))                   # log3(R_des R_q^T), R_des = I  (:616-627)
     X_nom, X_ter = centroidal_costs(gait, H, x_init, v_des, dt, amom)
-    dyn = Batch("solo12_trot_wb", B, H, E, model.total_mass, gait.rho, cnt, dt, x_init, X_nom, X_ter,
+    dyn = Batch(wb.name + "_" + gait.name + "_wb", B, H, E, model.total_mass, gait.rho, cnt, dt, x_init, X_nom, X_ter,
                 np.tile(gait.W_X, H)[None], gait.W_X_ter[None].copy(), np.tile(gait.W_F, H)[None],
-                np.tile(BOUNDS_TILE, (H, 1))[None], swing, np.zeros(B, dtype=np.int64), 1.0,
-                dict(seed=seed, first=first, t0=t0, v_des=v_des))
+                np.tile(BOUNDS_TILE, (H, 1))[None], swing, np.zeros(B, dtype=np.int64), wb.mu,
+                dict(seed=seed, first=first, t0=t0, v_des=v_des, v_des_body=v_des_b))
     # IK task blocks: 4 x {w, frame, ref3} | com {w, ref3} | mom {w, ref6} | state w | ctrl w
     fid = tuple(model.frame_id(n) for n in FEET)
     tasks = np.zeros((B, T + 1, 33))
@@ -417,6 +439,6 @@ def make_wb_batch(model, B, first=0, seed=None, gait=TROT, ik=TROT_IK, ik_hor_ra
     tasks[:, :, 31] = ik["reg_wt"][0]
     tasks[:, :, 32] = ik["reg_wt"][1]
     x = np.concatenate([q, v], axis=1)
-    x_reg = np.concatenate([np.tile(SOLO12_Q0, (B, 1)), np.zeros((B, 18))], axis=1)
+    x_reg = np.concatenate([np.tile(Q0, (B, 1)), np.zeros((B, 18))], axis=1)
     return WholeBodyBatch(dyn, x, T, tasks, ik["state_wt"][None].copy(), ik["ctrl_wt"][None].copy(), x_reg,
                           ik["cent_wt"][0], ik["cent_wt"][1], fid)

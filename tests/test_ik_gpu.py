@@ -135,12 +135,29 @@ def test_kinodyn_end_to_end(model, oracle):
     assert t.shape == (3,) and t[2] >= t[0] + t[1] > 0
 
 
+def _oracle_ddp(model, wb, i, X):
+    """numpy DDP on problem i of a whole-body batch, tracking the centroidal solution X (H+1, 9)"""
+    from oracle import ik_ddp_np
+    T, names = wb.ik_T, list(model.frames)
+    prob = ik_ddp_np.IKProblem(model, T)
+    for t in range(T + 1):
+        tk = wb.ik_tasks[i, t]
+        for s in range(4):
+            if tk[5 * s] != 0:
+                prob._add(t, "f%d" % s, ("frame", tk[5 * s], (names[int(tk[5 * s + 1])], tk[5 * s + 2:5 * s + 5])))
+        prob._add(t, "com", ("com", tk[20], X[t, 0:3]))
+        prob._add(t, "mom", ("mom", tk[24], np.concatenate([wb.dyn.m * X[t, 3:6], X[t, 6:9]])))
+        prob._add(t, "x", ("state", tk[31], (wb.state_w[0], wb.x_reg[i])))
+        prob._add(t, "u", ("ctrl", tk[32], wb.ctrl_w[0]))
+    prob.setup_costs(wb.dyn.dt[i, :T])
+    return ik_ddp_np.solve_ddp(prob, wb.x[i])
+
+
 def test_kinodyn_batch_matches_per_problem_oracle(model, oracle):
     """bmpc_kinodyn_solve_batch_device on perturbed whole-body states: every problem equals the
     strict centroidal oracle + numpy DDP run on that problem alone (problems finish at different
     DDP iterations inside one batch)."""
     from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
-    from oracle import ik_ddp_np
     B = 6
     wb = problems.make_wb_batch(model, B)
     kb = KinoDynDeviceBatch(wb, model, num_iters=10)
@@ -148,23 +165,38 @@ def test_kinodyn_batch_matches_per_problem_oracle(model, oracle):
     got = kb.results()
     ref = oracle.solve_batch(wb.dyn, num_iters=10)
     assert np.all(rel_l2(got["X"], ref["X"]) < 1e-5)
-    T, names = wb.ik_T, list(model.frames)
     assert np.all(got["ik_status"] == 0)
     for i in range(B):
-        X = ref["X"][i].reshape(-1, 9)
-        prob = ik_ddp_np.IKProblem(model, T)
-        for t in range(T + 1):
-            tk = wb.ik_tasks[i, t]
-            for s in range(4):
-                if tk[5 * s] != 0:
-                    prob._add(t, "f%d" % s, ("frame", tk[5 * s], (names[int(tk[5 * s + 1])], tk[5 * s + 2:5 * s + 5])))
-            prob._add(t, "com", ("com", tk[20], X[t, 0:3]))
-            prob._add(t, "mom", ("mom", tk[24], np.concatenate([wb.dyn.m * X[t, 3:6], X[t, 6:9]])))
-            prob._add(t, "x", ("state", tk[31], (wb.state_w[0], wb.x_reg[i])))
-            prob._add(t, "u", ("ctrl", tk[32], wb.ctrl_w[0]))
-        prob.setup_costs(wb.dyn.dt[i, :T])
-        r = ik_ddp_np.solve_ddp(prob, wb.x[i])
+        r = _oracle_ddp(model, wb, i, ref["X"][i].reshape(-1, 9))
         assert r["converged"] and got["ik_iters"][i] == r["iters"], (i, got["ik_iters"][i], r["iters"])
         assert abs(got["ik_cost"][i] - r["cost"]) <= 1e-7 * abs(r["cost"])
         assert rel_l2(got["xs"][i].reshape(-1), np.array(r["xs"]).reshape(-1)) < 1e-6
     print("ik iters per problem", got["ik_iters"], "loop iters", got["ddp_loop_iters"])
+
+
+def test_kinodyn_batch_go2_h60(oracle):
+    """BASELINE config 5 at test size: synthetic Go2 (tools/make_go2_model.py), trot, H=60, H_ik=30.
+    The centroidal part is compared in the long-horizon envelope (the two CPU
+    restatements themselves differ by ~1e-4 there); the IK-DDP is compared exactly, on the
+    references the GPU's own centroidal solution produced."""
+    import dataclasses
+    from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
+    go2 = urdf_model.RobotModel.from_json(open(ROBOT.replace("solo12.json", "go2.json")).read())
+    assert abs(go2.total_mass - 15.099) < 1e-9
+    gait = dataclasses.replace(problems.TROT, nom_ht=0.30, gait_horizon=6.0)
+    B = 2
+    wb = problems.make_wb_batch(go2, B, gait=gait, wb=problems.GO2_WB)
+    assert wb.dyn.H == 60 and wb.ik_T == 30
+    kb = KinoDynDeviceBatch(wb, go2, num_iters=10)
+    kb.solve()
+    got = kb.results()
+    ref = oracle.solve_batch(wb.dyn, num_iters=10)
+    assert np.all(rel_l2(got["X"], ref["X"]) < 5e-3) and np.all(np.isfinite(got["X"]))
+    assert np.array_equal(got["stats"][:, 0], ref["stats"][:, 0])        # same number of ADMM iterations
+    assert np.all(got["ik_status"] == 0)
+    for i in range(B):
+        r = _oracle_ddp(go2, wb, i, got["X"][i].reshape(-1, 9))
+        assert r["converged"] and got["ik_iters"][i] == r["iters"], (i, got["ik_iters"][i], r["iters"])
+        assert abs(got["ik_cost"][i] - r["cost"]) <= 1e-7 * abs(r["cost"])
+        assert rel_l2(got["xs"][i].reshape(-1), np.array(r["xs"]).reshape(-1)) < 1e-6
+    print("go2 ik iters", got["ik_iters"], "rel X", rel_l2(got["X"], ref["X"]))
