@@ -97,14 +97,31 @@ def p50_latency(config, num_iters, reps=60):
     return float(np.median(ts[5:]) * 1e3)
 
 
-def kinodyn_leg(dev, B, admm_iters, maxit, steps=3):
-    """Informational: the full KinoDynMP.optimize (centroidal ADMM + whole-body IK-DDP, Solo12 trot,
-    H = 20, H_ik = 10) over B perturbed whole-body states, device resident."""
+def pmc_traffic(workload_key):
+    """HBM bytes per launch measured with rocprofv3 PMC counters for exactly this workload
+    (profiles/pmc_traffic.json), or None when no such measurement is committed."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get(workload_key, {}).get("traffic_bytes")
+    except OSError:
+        return None
+
+
+def kinodyn_leg(dev, B, admm_iters, maxit, config="solo12_h20", steps=3):
+    """Informational: the full KinoDynMP.optimize (centroidal ADMM + whole-body IK-DDP) over B perturbed
+    whole-body states, device resident.  solo12_h20: Solo12 trot, H = 20, H_ik = 10;
+    go2_h60: BASELINE config 5's shape (synthetic Go2, trot, H = 60, H_ik = 30)."""
+    import dataclasses
     import torch
     from bunmpc_amd import problems, urdf_model
     from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
-    model = urdf_model.RobotModel.from_json(open(os.path.join(ROOT, "bunmpc_amd", "robots", "solo12.json")).read())
-    wb = problems.make_wb_batch(model, B)
+    robot = "go2" if config == "go2_h60" else "solo12"
+    model = urdf_model.RobotModel.from_json(open(os.path.join(ROOT, "bunmpc_amd", "robots", robot + ".json")).read())
+    if config == "go2_h60":
+        wb = problems.make_wb_batch(model, B, gait=dataclasses.replace(problems.TROT, nom_ht=0.30, gait_horizon=6.0),
+                                    wb=problems.GO2_WB)
+    else:
+        wb = problems.make_wb_batch(model, B)
     kb = KinoDynDeviceBatch(wb, model, device=dev, num_iters=admm_iters, maxit=maxit)
     kb.solve()
     torch.cuda.synchronize(dev)
@@ -119,7 +136,8 @@ def kinodyn_leg(dev, B, admm_iters, maxit, steps=3):
     torch.cuda.synchronize(dev)
     dt_ik = (time.perf_counter() - t1) / steps
     r = kb.results()
-    return {"value": B / dt, "unit": "KinoDynMP solves/s", "batch": B, "ms_per_step": dt * 1e3,
+    return {"value": B / dt, "unit": "KinoDynMP solves/s", "workload": "%s H=%d H_ik=%d" % (config, wb.dyn.H, wb.ik_T),
+            "batch": B, "ms_per_step": dt * 1e3,
             "ik_only_ms_per_step": dt_ik * 1e3, "ddp_iters_mean": float(r["ik_iters"].mean()),
             "ddp_iters_max": int(r["ik_iters"].max()), "ddp_not_converged": int((r["ik_status"] != 0).sum()),
             "admm_diverged": int((r["stats"][:, 5] != 0).sum())}
@@ -139,6 +157,10 @@ def main():
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-kinodyn", action="store_true")
     ap.add_argument("--kinodyn-batch", type=int, default=4096)
+    ap.add_argument("--kinodyn-config", default="solo12_h20", choices=["solo12_h20", "go2_h60"],
+                    help="solo12_h20: Solo12 trot H=20 / H_ik=10; go2_h60: BASELINE config 5 (synthetic Go2, H=60 / H_ik=30)")
+    ap.add_argument("--precision", default="f64", choices=["f64", "f32"],
+                    help="f32: BASELINE config 3's mixed-precision kernel (fp32 iterates, fp64 decisions)")
     args = ap.parse_args()
 
     import torch
@@ -160,7 +182,7 @@ def main():
     from bunmpc_amd import problems
     B = args.batch
     pb = problems.make_batch(args.config, B, first=rank * B)
-    db = bb.DeviceBatch(pb, device=dev, num_iters=args.admm_iters, maxit=args.maxit)
+    db = bb.DeviceBatch(pb, device=dev, num_iters=args.admm_iters, maxit=args.maxit, precision=args.precision)
 
     def sync():
         if world > 1:
@@ -194,17 +216,19 @@ def main():
         abytes = bb.algorithmic_bytes_per_solve(pb.H, pb.E, per_w) * B
         achieved = abytes / (kern_ms * 1e-3) / 1e9
         flops = float(counts[2]) / world  # per launch on one GPU
+        wkey = "%s H=%d B=%d admm_iters=%d fista_maxit=%d %s" % (args.config, pb.H, B, args.admm_iters, args.maxit, args.precision)
+        traffic = pmc_traffic(wkey)
         out = {
             "metric": "MPC solves/sec (batch, whole node), Solo12 trot H=20, 10 ADMM iters, fp64",
             "value": total / elapsed, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic",
             "config": {"workload": "%s H=%d B=%d/GPU admm_iters=%d fista_maxit=%d cold-start"
                                    % (args.config, pb.H, B, args.admm_iters, args.maxit),
                        "global_batch": B * world, "parallelism": "batch-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "biconvex_admm_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": abytes,
                          "valu": {"model_flops_per_launch": flops,
@@ -219,7 +243,7 @@ def main():
         if world == 1 and not args.no_latency:
             out["p50_latency_ms_batch1"] = p50_latency(args.config, args.admm_iters)
         if world == 1 and not args.no_kinodyn:
-            out["kinodyn_full_solve"] = kinodyn_leg(dev, args.kinodyn_batch, args.admm_iters, args.maxit)
+            out["kinodyn_full_solve"] = kinodyn_leg(dev, args.kinodyn_batch, args.admm_iters, args.maxit, args.kinodyn_config)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -21,7 +21,7 @@ class Batch(C.Structure):
     """bmpc_batch_t"""
     _fields_ = ([("B", C.c_int), ("n_col", C.c_int), ("n_eff", C.c_int), ("raw", C.c_int),
                  ("num_iters", C.c_int), ("maxit", C.c_int), ("cold_start", C.c_int),
-                 ("reserved_", C.c_int)] +
+                 ("precision", C.c_int)] +
                 [(n, C.c_double) for n in ("m", "rho", "mu", "beta", "tol", "exit_tol")] +
                 [(n, C.c_void_p) for n in ("cnt_plan", "dt", "x_init", "W_X", "W_X_ter", "W_F",
                                            "bounds", "X_nom", "X_ter")] +

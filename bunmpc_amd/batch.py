@@ -40,7 +40,7 @@ class DeviceBatch:
     create_cost_F / create_bound_constraints itself)."""
 
     def __init__(self, batch, device="cuda", num_iters=10, maxit=150, tol=1e-5, exit_tol=1e-3,
-                 beta=1.5, mu=None, keep_hist=False):
+                 beta=1.5, mu=None, keep_hist=False, precision="f64"):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("DeviceBatch needs a GPU: no CPU fallback exists for the solve")
@@ -69,6 +69,7 @@ class DeviceBatch:
         d = _lib.Batch()
         _lib.lib().bmpc_batch_defaults(C.byref(d))
         _solver_fields(d, batch, num_iters, maxit, tol, exit_tol, beta, mu)
+        d.precision = {"f64": 0, "f32": 1}[precision]
         d.raw = 0
         d.cold_start = 1
         for k, v in self.t.items():
@@ -111,7 +112,7 @@ class DeviceBatch:
 
 
 def solve_host(batch, num_iters=10, maxit=150, tol=1e-5, exit_tol=1e-3, beta=1.5, mu=None,
-               warm=None, L_x=None, L_f=None, raw=None, keep_hist=False):
+               warm=None, L_x=None, L_f=None, raw=None, keep_hist=False, precision="f64"):
     """numpy in / numpy out through bmpc_biconvex_solve_batch_host (copies in, one launch,
     copies out).  warm = (X, F, P) or None for a cold start.  raw = dict(Qx,qx,lbx,ubx,Qf[,qf])
     switches to the raw cost/bound form."""
@@ -127,6 +128,7 @@ def solve_host(batch, num_iters=10, maxit=150, tol=1e-5, exit_tol=1e-3, beta=1.5
     d = _lib.Batch()
     _lib.lib().bmpc_batch_defaults(C.byref(d))
     _solver_fields(d, batch, num_iters, maxit, tol, exit_tol, beta, mu)
+    d.precision = {"f64": 0, "f32": 1}[precision]
     for k in ("cnt_plan", "dt", "x_init"):
         setattr(d, k, f64(getattr(batch, k)).ctypes.data)
     if raw is None:

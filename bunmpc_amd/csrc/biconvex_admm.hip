@@ -15,7 +15,7 @@
 // MI355X mapping (this is not how the reference is organised):
 //   * one knot per lane, one problem per LPP-lane segment of a wave64
 //     (LPP = 16/32/64 >= H+1), so a wave carries 4/2/1 problems; 64-thread
-//     workgroups, B*LPP/64 of them -- no LDS, no barriers, no inter-workgroup traffic;
+//     workgroups, B*LPP/64 of them -- one barrier (momentum table), no inter-workgroup traffic;
 //   * matrix-free operators: lane t applies its own 6x12 block of A_x and its own
 //     block-row / block-column of the block-bidiagonal A_f; the explicit Hessian
 //     2(Q + rho A^T A) the reference rebuilds every ADMM iteration never exists;
@@ -27,10 +27,13 @@
 //   * the affine images A y + bPk are carried through the momentum step by
 //     linearity, so an iteration costs one A and one A^T application instead of the
 //     reference's three sparse mat-vecs;
-//   * fp64 throughout (MFMA has no advantage over VALU for fp64 on gfx950 and the
-//     blocks are 6x12 / 9x9 sparse), iterate state in VGPRs; X / F round-trip
-//     through their (L2-resident) output buffers at phase boundaries to keep the
-//     register footprint of each FISTA loop small.
+//   * fp64 arithmetic (R = double; MFMA has no advantage over VALU for fp64 on gfx950 and the
+//     blocks are 6x12 / 9x9 sparse), FISTA state in VGPRs; between phases X / F / P of a problem
+//     rest in LDS (each lane touches only its own knot's blocks), so HBM sees the inputs once and
+//     the results once;
+//   * R = float is the mixed-precision variant (BASELINE config 3): iterates, operators and
+//     projections in fp32, while every decision the algorithm takes -- the backtracking test,
+//     both exit tests, the dynamics violation -- is reduced and compared in fp64.  HBM keeps fp64.
 #include "biconvex_kernels.h"
 
 namespace bunmpc {
@@ -54,9 +57,13 @@ __device__ __forceinline__ double dpp_mov(double v) {
     hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 // value held by the previous / next knot's lane (0 at the wave ends)
-__device__ __forceinline__ double from_prev(double v) { return dpp_mov<DPP_WAVE_SHR1>(v); }
-__device__ __forceinline__ double from_next(double v) { return dpp_mov<DPP_WAVE_SHL1>(v); }
+template <typename R> __device__ __forceinline__ R from_prev(R v) { return dpp_mov<DPP_WAVE_SHR1>(v); }
+template <typename R> __device__ __forceinline__ R from_next(R v) { return dpp_mov<DPP_WAVE_SHL1>(v); }
 
 __device__ __forceinline__ double swap16_sum(double v) {
     unsigned lo = __double2loint(v), hi = __double2hiint(v);
@@ -84,13 +91,15 @@ __device__ __forceinline__ double seg_sum(double v) {
     return v;
 }
 
-__device__ __forceinline__ double ldz(const double *p, long i, bool ok) { return ok ? p[i] : 0.0; }
+// HBM holds fp64 whatever the arithmetic type R of the kernel; conversion happens at the load / store
+template <typename R> __device__ __forceinline__ R ldz(const double *p, long i, bool ok) { return ok ? (R)p[i] : R(0); }
 
 // v where m is all ones, +0.0 where m is 0 -- two v_and_b32, no branch, and (unlike a multiply by
 // 0/1) it also wipes NaN/inf, which keeps a diverged problem from leaking into its wave-mate
 __device__ __forceinline__ double keep_if(double v, int m) {
     return __hiloint2double(__double2hiint(v) & m, __double2loint(v) & m);
 }
+__device__ __forceinline__ float keep_if(float v, int m) { return __int_as_float(__float_as_int(v) & m); }
 
 // a / b to ~1 ulp without the IEEE division sequence: v_rcp_f64 (2^-26 or better) + two Newton
 // steps + one residual correction.  Used only inside the cone branch of the projection.
@@ -101,6 +110,15 @@ __device__ __forceinline__ double fast_div(double a, double b) {
     const double q = a * r;
     return fma(fma(-b, q, a), r, q);
 }
+__device__ __forceinline__ float fast_div(float a, float b) { return a / b; }
+
+// type-exact fma / min / max (the unsuffixed C names would promote float operands to double)
+__device__ __forceinline__ double fmaR(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fmaR(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fmaxR(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ float fmaxR(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double fminR(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ float fminR(float a, float b) { return __builtin_fminf(a, b); }
 
 constexpr double kGravity = 9.81;  // centroidal.cpp:63
 
@@ -118,9 +136,10 @@ constexpr double kGravity = 9.81;  // centroidal.cpp:63
 //     only; each wave tabulates them once in LDS.
 //   * a problem that finishes (|d| < tol or maxit) has its iterate latched into `fin` registers
 //     at that moment; the loop body itself carries no per-lane freeze selects.
-template <int LPP, int E, bool RAW, bool HASQF>
+template <typename R, int LPP, int E, bool RAW, bool HASQF>
 __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
-    extern __shared__ double cmtab[];   // [maxit]
+    extern __shared__ double lds_raw[];
+    R *cmtab = reinterpret_cast<R *>(lds_raw);   // [maxit]
     constexpr int NF = 3 * E;           // force variables per knot
     constexpr int NB = RAW ? 9 : 3;     // bounded components per knot
     const int lane = threadIdx.x & 63;
@@ -135,19 +154,19 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
     const long nx = 9L * (H + 1), nf = (long)NF * H;
     const long pb = pvalid ? prob : 0;
 
-    const double m = a.c.m, rho = a.c.rho, mu = a.c.mu, beta = a.c.beta;
-    const double tol = a.c.tol, exit_tol = a.c.exit_tol;
+    const R m = (R)a.c.m, rho = (R)a.c.rho, mu = (R)a.c.mu, beta = (R)a.c.beta;
+    const double tol = a.c.tol, exit_tol = a.c.exit_tol;   // exit tests are evaluated in fp64 whatever R is
     const int maxit = a.c.maxit;
-    const double rho2 = 2.0 * rho;
+    const R rho2 = R(2) * rho;
 
     // Iterates at phase boundaries (X, F, P of this segment's problem) live in LDS, each lane touching
     // only its own knot's blocks (lane 0 also the x_init rows of P): HBM sees the inputs once and the
     // results once.  Layout after the momentum table: per segment [X nx | P nx | F nf].
-    double *seg_lds = cmtab + ((maxit + 1) & ~1) + (long)seg * (2 * nx + nf);
-    double *Xg = seg_lds + 9L * t;
-    double *Pg = seg_lds + nx + 9L * t;
-    double *PIg = seg_lds + nx + 9L * H;
-    double *Fg = seg_lds + 2 * nx + (long)NF * t;
+    R *seg_lds = cmtab + ((maxit + 1) & ~1) + (long)seg * (2 * nx + nf);
+    R *Xg = seg_lds + 9L * t;
+    R *Pg = seg_lds + nx + 9L * t;
+    R *PIg = seg_lds + nx + 9L * H;
+    R *Fg = seg_lds + 2 * nx + (long)NF * t;
     double *Xout = a.X + pb * nx + 9L * t, *Fout = a.F + pb * nf + (long)NF * t, *Pout = a.P + pb * nx + 9L * t;
     double *PIout = a.P + pb * nx + 9L * H;
 
@@ -155,31 +174,31 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
         double tk = 1.0;
         for (int i = 0; i < maxit; ++i) {
             const double tk1 = 1.0 + sqrt(1.0 + 4.0 * tk * tk) * 0.5;
-            if (lane == 0) cmtab[i] = (tk - 1.0) / tk1;
+            if (lane == 0) cmtab[i] = (R)((tk - 1.0) / tk1);
             tk = tk1;
         }
         __syncthreads();
     }
 
-    const double dt = ldz(a.dt, pb * H + t, rvalid);
-    const double dtp = from_prev(dt);  // dt of knot t-1 (0 for t == 0: previous lane is a dead/terminal lane)
+    const R dt = ldz<R>(a.dt, pb * H + t, rvalid);
+    const R dtp = from_prev(dt);  // dt of knot t-1 (0 for t == 0: previous lane is a dead/terminal lane)
     const bool cold = a.cold_start != 0;
-    double L_x = cold ? a.L0_x : (pvalid ? a.L_x[pb] : 1.0);
-    double L_f = cold ? a.L0_f : (pvalid ? a.L_f[pb] : 1.0);
+    R L_x = (R)(cold ? a.L0_x : (pvalid ? a.L_x[pb] : 1.0));
+    R L_f = (R)(cold ? a.L0_f : (pvalid ? a.L_f[pb] : 1.0));
     if (cold) {  // KinoDynMP::set_warm_starts (kino_dyn.cpp:83-99): X = tile(x_init), F = 0, P = 0
-        if (kvalid) { UNROLL for (int l = 0; l < 9; ++l) Xg[l] = a.x_init[pb * 9 + l]; }
+        if (kvalid) { UNROLL for (int l = 0; l < 9; ++l) Xg[l] = (R)a.x_init[pb * 9 + l]; }
         if (rvalid) {
-            UNROLL for (int j = 0; j < NF; ++j) Fg[j] = 0.0;
-            UNROLL for (int l = 0; l < 9; ++l) Pg[l] = 0.0;
+            UNROLL for (int j = 0; j < NF; ++j) Fg[j] = R(0);
+            UNROLL for (int l = 0; l < 9; ++l) Pg[l] = R(0);
         }
-        if (l0) { UNROLL for (int l = 0; l < 9; ++l) PIg[l] = 0.0; }
+        if (l0) { UNROLL for (int l = 0; l < 9; ++l) PIg[l] = R(0); }
     } else {     // set_warm_start_vars: bring the caller's iterates on chip
-        if (kvalid) { UNROLL for (int l = 0; l < 9; ++l) Xg[l] = Xout[l]; }
+        if (kvalid) { UNROLL for (int l = 0; l < 9; ++l) Xg[l] = (R)Xout[l]; }
         if (rvalid) {
-            UNROLL for (int j = 0; j < NF; ++j) Fg[j] = Fout[j];
-            UNROLL for (int l = 0; l < 9; ++l) Pg[l] = Pout[l];
+            UNROLL for (int j = 0; j < NF; ++j) Fg[j] = (R)Fout[j];
+            UNROLL for (int l = 0; l < 9; ++l) Pg[l] = (R)Pout[l];
         }
-        if (l0) { UNROLL for (int l = 0; l < 9; ++l) PIg[l] = PIout[l]; }
+        if (l0) { UNROLL for (int l = 0; l < 9; ++l) PIg[l] = (R)PIout[l]; }
     }
     bool alive = pvalid;
     int n_admm = 0, it_f = 0, it_x = 0, bt_f = 0, bt_x = 0, status = 0;
@@ -193,39 +212,39 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
 
         // =================================================================== F step
         {
-            double c[E], r[E][3];
+            R c[E], r[E][3];
             UNROLL for (int n = 0; n < E; ++n) {
-                c[n] = ldz(cg, 4 * n, rvalid);
-                UNROLL for (int k = 0; k < 3; ++k) r[n][k] = ldz(cg, 4 * n + 1 + k, rvalid);
+                c[n] = ldz<R>(cg, 4 * n, rvalid);
+                UNROLL for (int k = 0; k < 3; ++k) r[n][k] = ldz<R>(cg, 4 * n + 1 + k, rvalid);
             }
-            double X[9];
-            UNROLL for (int l = 0; l < 9; ++l) X[l] = kvalid ? Xg[l] : 0.0;
+            R X[9];
+            UNROLL for (int l = 0; l < 9; ++l) X[l] = kvalid ? Xg[l] : R(0);
             // bPk rows 9t+3..8 = -b_x + P, b_x = X_{t+1} - X_t (+g dt)   (centroidal.cpp:60-65)
-            double bpk[6];
+            R bpk[6];
             UNROLL for (int k = 0; k < 6; ++k) {
-                const double xn = from_next(X[3 + k]);
-                double bx = xn - X[3 + k];
-                if (k == 2) bx += kGravity * dt;
-                bpk[k] = rvalid ? (-bx + Pg[3 + k]) : 0.0;
+                const R xn = from_next(X[3 + k]);
+                R bx = xn - X[3 + k];
+                if (k == 2) bx += R(kGravity) * dt;
+                bpk[k] = rvalid ? (-bx + Pg[3 + k]) : R(0);
             }
             // A_x entries of this knot (centroidal.cpp:67-81)
-            double an[E], sp[E][3];
+            R an[E], sp[E][3];
             UNROLL for (int n = 0; n < E; ++n) {
                 an[n] = c[n] * (dt / m);
                 UNROLL for (int k = 0; k < 3; ++k) sp[n][k] = c[n] * (X[k] - r[n][k]) * dt;
             }
-            double wf[NF], wf2[NF], qf[HASQF ? NF : 1];
+            R wf[NF], wf2[NF], qf[HASQF ? NF : 1];
             UNROLL for (int j = 0; j < NF; ++j) {
-                wf[j] = RAW ? ldz(a.Qf, pb * nf + (long)NF * t + j, rvalid)
-                            : ldz(a.W_F, pb * a.sW_F + (long)NF * t + j, rvalid);
-                wf2[j] = 2.0 * wf[j];
-                if (HASQF) qf[j] = ldz(a.qf, pb * nf + (long)NF * t + j, rvalid);
+                wf[j] = RAW ? ldz<R>(a.Qf, pb * nf + (long)NF * t + j, rvalid)
+                            : ldz<R>(a.W_F, pb * a.sW_F + (long)NF * t + j, rvalid);
+                wf2[j] = R(2) * wf[j];
+                if (HASQF) qf[j] = ldz<R>(a.qf, pb * nf + (long)NF * t + j, rvalid);
             }
             // u = A v + bPk on rows 9t+3..8
-            auto applyA = [&](const double (&v)[NF], double (&u)[6]) {
-                double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
+            auto applyA = [&](const R (&v)[NF], R (&u)[6]) {
+                R s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
                 UNROLL for (int n = 0; n < E; ++n) {
-                    const double vx = v[3 * n], vy = v[3 * n + 1], vz = v[3 * n + 2];
+                    const R vx = v[3 * n], vy = v[3 * n + 1], vz = v[3 * n + 2];
                     s0 += an[n] * vx; s1 += an[n] * vy; s2 += an[n] * vz;
                     s3 += sp[n][2] * vy - sp[n][1] * vz;
                     s4 += sp[n][0] * vz - sp[n][2] * vx;
@@ -237,26 +256,26 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
 
             // FISTA state.  x lives in two buffers (xa/xb, A-images ra/rb) whose roles swap every
             // iteration, so "x_k = x_k_1" (fista.cpp:37) costs no register moves.
-            double xa[NF], xb[NF], y[NF], ra[6], rb[6], ry[6];
-            UNROLL for (int j = 0; j < NF; ++j) { xa[j] = rvalid ? Fg[j] : 0.0; y[j] = xa[j]; }
+            R xa[NF], xb[NF], y[NF], ra[6], rb[6], ry[6];
+            UNROLL for (int j = 0; j < NF; ++j) { xa[j] = rvalid ? Fg[j] : R(0); y[j] = xa[j]; }
             applyA(y, ry);
             UNROLL for (int k = 0; k < 6; ++k) ra[k] = ry[k];
-            const double mu2 = mu * mu, imu = 1.0 / (mu * mu + 1.0);
+            const R mu2 = mu * mu, imu = R(1) / (mu * mu + R(1));
             const double tol2 = tol * tol;
-            double invL = 1.0 / L_f;
+            R invL = R(1) / L_f;
             bool act = alive;
             // one FISTA iteration: reads x from xo/ro, leaves x_{k+1} in xn/rn, advances y/ry
-            auto iterate = [&](const double (&xo)[NF], const double (&ro)[6], double (&xn)[NF], double (&rn)[6], int i) {
-                const double cm = cmtab[i];
+            auto iterate = [&](const R (&xo)[NF], const R (&ro)[6], R (&xn)[NF], R (&rn)[6], int i) {
+                const R cm = cmtab[i];
                 // g = 2 Q y + q + 2 rho A^T (A y + bPk)          (problem.cpp:36-38,54-56)
-                double gs[NF];
+                R gs[NF];
                 UNROLL for (int n = 0; n < E; ++n) {
-                    const double zx = an[n] * ry[0] - sp[n][2] * ry[4] + sp[n][1] * ry[5];
-                    const double zy = an[n] * ry[1] + sp[n][2] * ry[3] - sp[n][0] * ry[5];
-                    const double zz = an[n] * ry[2] - sp[n][1] * ry[3] + sp[n][0] * ry[4];
-                    gs[3 * n] = fma(wf2[3 * n], y[3 * n], rho2 * zx);
-                    gs[3 * n + 1] = fma(wf2[3 * n + 1], y[3 * n + 1], rho2 * zy);
-                    gs[3 * n + 2] = fma(wf2[3 * n + 2], y[3 * n + 2], rho2 * zz);
+                    const R zx = an[n] * ry[0] - sp[n][2] * ry[4] + sp[n][1] * ry[5];
+                    const R zy = an[n] * ry[1] + sp[n][2] * ry[3] - sp[n][0] * ry[5];
+                    const R zz = an[n] * ry[2] - sp[n][1] * ry[3] + sp[n][0] * ry[4];
+                    gs[3 * n] = fmaR(wf2[3 * n], y[3 * n], rho2 * zx);
+                    gs[3 * n + 1] = fmaR(wf2[3 * n + 1], y[3 * n + 1], rho2 * zy);
+                    gs[3 * n + 2] = fmaR(wf2[3 * n + 2], y[3 * n + 2], rho2 * zz);
                     if (HASQF) { gs[3 * n] += qf[3 * n]; gs[3 * n + 1] += qf[3 * n + 1]; gs[3 * n + 2] += qf[3 * n + 2]; }
                 }
                 bool done;
@@ -264,65 +283,64 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
                 for (;;) {  // backtracking (fista.cpp:8-26); segments that accepted recompute the same values
                     // "SoC" projection exactly as fista.cpp:52-70 writes it
                     bool anycone = false;
-                    double fr[NF];
-                    UNROLL for (int j = 0; j < NF; ++j) fr[j] = fma(-gs[j], invL, y[j]);
+                    R fr[NF];
+                    UNROLL for (int j = 0; j < NF; ++j) fr[j] = fmaR(-gs[j], invL, y[j]);
                     UNROLL for (int n = 0; n < E; ++n) {
-                        const double s = fma(fr[3 * n], fr[3 * n], fr[3 * n + 1] * fr[3 * n + 1]);
-                        const double fz = fr[3 * n + 2];
+                        const R s = fmaR(fr[3 * n], fr[3 * n], fr[3 * n + 1] * fr[3 * n + 1]);
+                        const R fz = fr[3 * n + 2];
                         const bool zero = (s * mu < -fz) || (fz < 0);
                         anycone = anycone || (!zero && (s > mu * fz));
-                        xn[3 * n] = zero ? 0.0 : fr[3 * n];
-                        xn[3 * n + 1] = zero ? 0.0 : fr[3 * n + 1];
-                        xn[3 * n + 2] = zero ? 0.0 : fz;
+                        xn[3 * n] = zero ? R(0) : fr[3 * n];
+                        xn[3 * n + 1] = zero ? R(0) : fr[3 * n + 1];
+                        xn[3 * n + 2] = zero ? R(0) : fz;
                     }
                     if (__any(anycone)) {   // cone branch (fista.cpp:64-68); skipped while no lane needs it
                         UNROLL for (int n = 0; n < E; ++n) {
-                            const double s = fma(fr[3 * n], fr[3 * n], fr[3 * n + 1] * fr[3 * n + 1]);
-                            const double fz = fr[3 * n + 2];
+                            const R s = fmaR(fr[3 * n], fr[3 * n], fr[3 * n + 1] * fr[3 * n + 1]);
+                            const R fz = fr[3 * n + 2];
                             const bool zero = (s * mu < -fz) || (fz < 0);
                             const bool cone = !zero && (s > mu * fz);
-                            const double k = fast_div(fma(mu2, s, mu * fz), (mu2 + 1.0) * s);
+                            const R k = fast_div(fmaR(mu2, s, mu * fz), (mu2 + R(1)) * s);
                             xn[3 * n] = cone ? fr[3 * n] * k : xn[3 * n];
                             xn[3 * n + 1] = cone ? fr[3 * n + 1] * k : xn[3 * n + 1];
-                            xn[3 * n + 2] = cone ? fma(mu, s, fz) * imu : xn[3 * n + 2];
+                            xn[3 * n + 2] = cone ? fmaR(mu, s, fz) * imu : xn[3 * n + 2];
                         }
                     }
                     applyA(xn, rn);
-                    double g2 = 0, cv = 0, e2 = 0;
+                    R g2 = 0, cv = 0, e2 = 0;
                     UNROLL for (int j = 0; j < NF; ++j) {
-                        const double d = xn[j] - y[j];
-                        g2 = fma(d, d, g2);
-                        cv = fma(wf[j] * d, d, cv);
+                        const R d = xn[j] - y[j];
+                        g2 = fmaR(d, d, g2);
+                        cv = fmaR(wf[j] * d, d, cv);
                     }
-                    UNROLL for (int k = 0; k < 6; ++k) { const double e = rn[k] - ry[k]; e2 = fma(e, e, e2); }
-                    cv = fma(rho, e2, cv);
-                    g2 = seg_sum<LPP>(g2);
-                    cv = seg_sum<LPP>(cv);
+                    UNROLL for (int k = 0; k < 6; ++k) { const R e = rn[k] - ry[k]; e2 = fmaR(e, e, e2); }
+                    cv = fmaR(rho, e2, cv);
+                    const double g2s = seg_sum<LPP>((double)g2), cvs = seg_sum<LPP>((double)cv);
                     // fista.cpp:14-17: G = sqrt(g2); retry if cv > (L/2) G*G; done if G < tol.  G*G and g2
                     // differ by a few ulp, so outside a 1e-14 relative band the sqrt cannot change either
                     // decision; inside it the reference expression is evaluated as written.
-                    const double rhs = (L_f * 0.5) * g2;
-                    bool bt = cv > rhs;
-                    done = g2 < tol2;
-                    const bool edge = (fabs(cv - rhs) <= 1e-14 * rhs) || (fabs(g2 - tol2) <= 1e-14 * tol2);
+                    const double Lh = (double)L_f * 0.5, rhs = Lh * g2s;
+                    bool bt = cvs > rhs;
+                    done = g2s < tol2;
+                    const bool edge = (fabs(cvs - rhs) <= 1e-14 * rhs) || (fabs(g2s - tol2) <= 1e-14 * tol2);
                     if (__any(edge)) {
-                        const double Gn = sqrt(g2);
-                        bt = cv > (L_f * 0.5) * (Gn * Gn);
+                        const double Gn = sqrt(g2s);
+                        bt = cvs > Lh * (Gn * Gn);
                         done = Gn < tol;
                     }
                     bt = bt && pend;
                     pend = bt;
                     if (!__any(bt)) break;
                     if (bt) { L_f *= beta; ++bt_f; }
-                    invL = 1.0 / L_f;
+                    invL = R(1) / L_f;
                 }
                 const bool last = act && (done || i == maxit - 1);
                 if (__any(last)) {   // x_k of a finishing problem goes straight to its output block
                     if (last && rvalid) { UNROLL for (int j = 0; j < NF; ++j) Fg[j] = xn[j]; }
                 }
                 // momentum (fista.cpp:33-47); A-images follow by linearity
-                UNROLL for (int j = 0; j < NF; ++j) y[j] = fma(cm, xn[j] - xo[j], xn[j]);
-                UNROLL for (int k = 0; k < 6; ++k) ry[k] = fma(cm, rn[k] - ro[k], rn[k]);
+                UNROLL for (int j = 0; j < NF; ++j) y[j] = fmaR(cm, xn[j] - xo[j], xn[j]);
+                UNROLL for (int k = 0; k < 6; ++k) ry[k] = fmaR(cm, rn[k] - ro[k], rn[k]);
                 it_f += act ? 1 : 0;
                 act = act && !done;
             };
@@ -336,18 +354,18 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
 
         // =================================================================== X step
         {
-            double c[E], r[E][3];
+            R c[E], r[E][3];
             UNROLL for (int n = 0; n < E; ++n) {
-                c[n] = ldz(cg, 4 * n, rvalid);
-                UNROLL for (int k = 0; k < 3; ++k) r[n][k] = ldz(cg, 4 * n + 1 + k, rvalid);
+                c[n] = ldz<R>(cg, 4 * n, rvalid);
+                UNROLL for (int k = 0; k < 3; ++k) r[n][k] = ldz<R>(cg, 4 * n + 1 + k, rvalid);
             }
             // A_f / b_f entries of this knot from the new forces (centroidal.cpp:86-127)
-            double SX = 0, SY = 0, SZ = 0, bf[9];
+            R SX = 0, SY = 0, SZ = 0, bf[9];
             {
-                double b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0, b8 = 0;
+                R b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0, b8 = 0;
                 UNROLL for (int n = 0; n < E; ++n) {
-                    const double fx = rvalid ? Fg[3 * n] : 0.0, fy = rvalid ? Fg[3 * n + 1] : 0.0,
-                                 fz = rvalid ? Fg[3 * n + 2] : 0.0;
+                    const R fx = rvalid ? Fg[3 * n] : R(0), fy = rvalid ? Fg[3 * n + 1] : R(0),
+                            fz = rvalid ? Fg[3 * n + 2] : R(0);
                     SX += c[n] * fx * dt; SY += c[n] * fy * dt; SZ += c[n] * fz * dt;
                     b3 += -c[n] * fx * dt / m; b4 += -c[n] * fy * dt / m; b5 += -c[n] * fz * dt / m;
                     b6 += (c[n] * fy * r[n][2] - c[n] * fz * r[n][1]) * dt;
@@ -355,52 +373,52 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
                     b8 += (c[n] * fx * r[n][1] - c[n] * fy * r[n][0]) * dt;
                 }
                 bf[0] = 0; bf[1] = 0; bf[2] = 0;
-                bf[3] = b3; bf[4] = b4; bf[5] = b5 + kGravity * dt;
+                bf[3] = b3; bf[4] = b4; bf[5] = b5 + R(kGravity) * dt;
                 bf[6] = b6; bf[7] = b7; bf[8] = b8;
             }
-            double bpk[9];
-            UNROLL for (int l = 0; l < 9; ++l) bpk[l] = rvalid ? (-bf[l] + Pg[l]) : 0.0;
+            R bpk[9];
+            UNROLL for (int l = 0; l < 9; ++l) bpk[l] = rvalid ? (-bf[l] + Pg[l]) : R(0);
             // cost and bounds of this knot
-            double qd[9], q[9], lb[NB], ub[NB];
+            R qd[9], q[9], lb[NB], ub[NB];
             if (RAW) {
                 UNROLL for (int l = 0; l < 9; ++l) {
-                    qd[l] = ldz(a.Qx, pb * nx + 9L * t + l, kvalid);
-                    q[l] = ldz(a.qx, pb * nx + 9L * t + l, kvalid);
+                    qd[l] = ldz<R>(a.Qx, pb * nx + 9L * t + l, kvalid);
+                    q[l] = ldz<R>(a.qx, pb * nx + 9L * t + l, kvalid);
                 }
                 UNROLL for (int l = 0; l < NB; ++l) {
-                    lb[l] = kvalid ? a.lbx[pb * nx + 9L * t + l] : -INFINITY;
-                    ub[l] = kvalid ? a.ubx[pb * nx + 9L * t + l] : INFINITY;
+                    lb[l] = kvalid ? (R)a.lbx[pb * nx + 9L * t + l] : R(-INFINITY);
+                    ub[l] = kvalid ? (R)a.ubx[pb * nx + 9L * t + l] : R(INFINITY);
                 }
             } else {
                 // create_cost_X (biconvex.cpp:57-72)
                 UNROLL for (int l = 0; l < 9; ++l) {
-                    const double w = rvalid ? a.W_X[pb * a.sW_X + 9L * t + l]
-                                            : (kvalid ? a.W_X_ter[pb * a.sW_X_ter + l] : 0.0);
-                    const double xr = rvalid ? a.X_nom[pb * 9L * H + 9L * t + l]
-                                             : (kvalid ? a.X_ter[pb * 9 + l] : 0.0);
+                    const R w = (R)(rvalid ? a.W_X[pb * a.sW_X + 9L * t + l]
+                                                : (kvalid ? a.W_X_ter[pb * a.sW_X_ter + l] : 0.0));
+                    const R xr = (R)(rvalid ? a.X_nom[pb * 9L * H + 9L * t + l]
+                                                 : (kvalid ? a.X_ter[pb * 9 + l] : 0.0));
                     qd[l] = w;
-                    q[l] = -2.0 * (xr * w);
+                    q[l] = R(-2) * (xr * w);
                 }
                 // create_bound_constraints (biconvex.cpp:27-55): CoM box around the feet
-                double csum = 0;
+                R csum = 0;
                 UNROLL for (int n = 0; n < E; ++n) csum += c[n];
                 const bool bounded = rvalid && csum > 0;
                 UNROLL for (int k = 0; k < 3; ++k) {
-                    double mx = r[0][k], mn = r[0][k];
-                    UNROLL for (int n = 1; n < E; ++n) { mx = fmax(mx, r[n][k]); mn = fmin(mn, r[n][k]); }
-                    const double blo = bounded ? a.bounds[pb * a.sbounds + 6L * t + k] : 0.0;
-                    const double bhi = bounded ? a.bounds[pb * a.sbounds + 6L * t + 3 + k] : 0.0;
-                    lb[k] = bounded ? mx + blo : -INFINITY;
-                    ub[k] = bounded ? mn + bhi : INFINITY;
+                    R mx = r[0][k], mn = r[0][k];
+                    UNROLL for (int n = 1; n < E; ++n) { mx = fmaxR(mx, r[n][k]); mn = fminR(mn, r[n][k]); }
+                    const R blo = (R)(bounded ? a.bounds[pb * a.sbounds + 6L * t + k] : 0.0);
+                    const R bhi = (R)(bounded ? a.bounds[pb * a.sbounds + 6L * t + 3 + k] : 0.0);
+                    lb[k] = bounded ? mx + blo : R(-INFINITY);
+                    ub[k] = bounded ? mn + bhi : R(INFINITY);
                 }
             }
             // x_init rows folded into lane 0's diagonal cost:  rho |X_0 + (P_H - x_init)|^2
-            double qd2[9];
+            R qd2[9];
             UNROLL for (int l = 0; l < 9; ++l) {
-                const double bpi = l0 ? (PIg[l] - a.x_init[pb * 9 + l]) : 0.0;
-                qd[l] += l0 ? rho : 0.0;
+                const R bpi = l0 ? (PIg[l] - (R)a.x_init[pb * 9 + l]) : R(0);
+                qd[l] += l0 ? rho : R(0);
                 q[l] += rho2 * bpi;
-                qd2[l] = 2.0 * qd[l];
+                qd2[l] = R(2) * qd[l];
             }
             UNROLL for (int l = 0; l < NB; ++l) {   // quieted once, so the clamp is a bare min/max pair
                 lb[l] = __builtin_canonicalize(lb[l]);
@@ -408,10 +426,10 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
             }
             const int rmask = rvalid ? -1 : 0;      // row-block mask: lanes t >= H own no dynamics rows
             // u = A_f v + bPk on row-block t; vn = v of knot t+1
-            auto applyA = [&](const double (&v)[9], double (&u)[9]) {
-                double vn[9];
+            auto applyA = [&](const R (&v)[9], R (&u)[9]) {
+                R vn[9];
                 UNROLL for (int l = 0; l < 9; ++l) vn[l] = from_next(v[l]);
-                double w[9];
+                R w[9];
                 UNROLL for (int l = 0; l < 9; ++l) w[l] = v[l] - vn[l];
                 UNROLL for (int k = 0; k < 3; ++k) w[k] += dt * vn[3 + k];
                 w[6] += SY * v[2] - SZ * v[1];
@@ -420,68 +438,67 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
                 UNROLL for (int l = 0; l < 9; ++l) u[l] = keep_if(w[l] + bpk[l], rmask);
             };
 
-            double xa[9], xb[9], y[9], ra[9], rb[9], ry[9];
-            UNROLL for (int l = 0; l < 9; ++l) { xa[l] = kvalid ? Xg[l] : 0.0; y[l] = xa[l]; }
+            R xa[9], xb[9], y[9], ra[9], rb[9], ry[9];
+            UNROLL for (int l = 0; l < 9; ++l) { xa[l] = kvalid ? Xg[l] : R(0); y[l] = xa[l]; }
             applyA(y, ry);
             UNROLL for (int l = 0; l < 9; ++l) ra[l] = ry[l];
             const double tol2 = tol * tol;
-            double invL = 1.0 / L_x;
+            R invL = R(1) / L_x;
             bool act = alive;
-            auto iterate = [&](const double (&xo)[9], const double (&ro)[9], double (&xn)[9], double (&rn)[9], int i) {
-                const double cm = cmtab[i];
-                double gs[9];
+            auto iterate = [&](const R (&xo)[9], const R (&ro)[9], R (&xn)[9], R (&rn)[9], int i) {
+                const R cm = cmtab[i];
+                R gs[9];
                 {   // gradient 2 Q y + q + 2 rho A_f^T (A_f y + bPk)
-                    double z[9], wp[9];
+                    R z[9], wp[9];
                     UNROLL for (int l = 0; l < 9; ++l) wp[l] = from_prev(ry[l]);  // row-block t-1 (0 for t == 0)
                     UNROLL for (int l = 0; l < 9; ++l) z[l] = ry[l] - wp[l];
-                    UNROLL for (int k = 0; k < 3; ++k) z[3 + k] = fma(dtp, wp[k], z[3 + k]);
+                    UNROLL for (int k = 0; k < 3; ++k) z[3 + k] = fmaR(dtp, wp[k], z[3 + k]);
                     z[0] += SZ * ry[7] - SY * ry[8];
                     z[1] += SX * ry[8] - SZ * ry[6];
                     z[2] += SY * ry[6] - SX * ry[7];
-                    UNROLL for (int l = 0; l < 9; ++l) gs[l] = fma(qd2[l], y[l], fma(rho2, z[l], q[l]));
+                    UNROLL for (int l = 0; l < 9; ++l) gs[l] = fmaR(qd2[l], y[l], fmaR(rho2, z[l], q[l]));
                 }
                 bool done;
                 bool pend = act;
                 for (;;) {
                     UNROLL for (int l = 0; l < 9; ++l) {
-                        double v = fma(-gs[l], invL, y[l]);
-                        if (l < NB) v = fmax(fmin(v, ub[l]), lb[l]);   // fista.cpp:10
+                        R v = fmaR(-gs[l], invL, y[l]);
+                        if (l < NB) v = fmaxR(fminR(v, ub[l]), lb[l]);   // fista.cpp:10
                         xn[l] = v;
                     }
                     applyA(xn, rn);
-                    double g2 = 0, cv = 0, e2 = 0;
+                    R g2 = 0, cv = 0, e2 = 0;
                     UNROLL for (int l = 0; l < 9; ++l) {
-                        const double d = xn[l] - y[l];
-                        const double e = rn[l] - ry[l];
-                        g2 = fma(d, d, g2);
-                        cv = fma(qd[l] * d, d, cv);
-                        e2 = fma(e, e, e2);
+                        const R d = xn[l] - y[l];
+                        const R e = rn[l] - ry[l];
+                        g2 = fmaR(d, d, g2);
+                        cv = fmaR(qd[l] * d, d, cv);
+                        e2 = fmaR(e, e, e2);
                     }
-                    cv = fma(rho, e2, cv);
-                    g2 = seg_sum<LPP>(g2);
-                    cv = seg_sum<LPP>(cv);
-                    const double rhs = (L_x * 0.5) * g2;   // see the force loop for the sqrt-free form
-                    bool bt = cv > rhs;
-                    done = g2 < tol2;
-                    const bool edge = (fabs(cv - rhs) <= 1e-14 * rhs) || (fabs(g2 - tol2) <= 1e-14 * tol2);
+                    cv = fmaR(rho, e2, cv);
+                    const double g2s = seg_sum<LPP>((double)g2), cvs = seg_sum<LPP>((double)cv);
+                    const double Lh = (double)L_x * 0.5, rhs = Lh * g2s;   // see the force loop for the sqrt-free form
+                    bool bt = cvs > rhs;
+                    done = g2s < tol2;
+                    const bool edge = (fabs(cvs - rhs) <= 1e-14 * rhs) || (fabs(g2s - tol2) <= 1e-14 * tol2);
                     if (__any(edge)) {
-                        const double Gn = sqrt(g2);
-                        bt = cv > (L_x * 0.5) * (Gn * Gn);
+                        const double Gn = sqrt(g2s);
+                        bt = cvs > Lh * (Gn * Gn);
                         done = Gn < tol;
                     }
                     bt = bt && pend;
                     pend = bt;
                     if (!__any(bt)) break;
                     if (bt) { L_x *= beta; ++bt_x; }
-                    invL = 1.0 / L_x;
+                    invL = R(1) / L_x;
                 }
                 const bool last = act && (done || i == maxit - 1);
                 if (__any(last)) {
                     if (last && kvalid) { UNROLL for (int l = 0; l < 9; ++l) Xg[l] = xn[l]; }
                 }
                 UNROLL for (int l = 0; l < 9; ++l) {
-                    y[l] = fma(cm, xn[l] - xo[l], xn[l]);
-                    ry[l] = fma(cm, rn[l] - ro[l], rn[l]);
+                    y[l] = fmaR(cm, xn[l] - xo[l], xn[l]);
+                    ry[l] = fmaR(cm, rn[l] - ro[l], rn[l]);
                 }
                 it_x += act ? 1 : 0;
                 act = act && !done;
@@ -492,13 +509,13 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
                 if (i + 1 >= maxit || !__any(act)) break;
                 iterate(xb, rb, xa, ra, i + 1);
             }
-            double fin[9];
-            UNROLL for (int l = 0; l < 9; ++l) fin[l] = kvalid ? Xg[l] : 0.0;
+            R fin[9];
+            UNROLL for (int l = 0; l < 9; ++l) fin[l] = kvalid ? Xg[l] : R(0);
 
             // dyn_violation = A_f X - b_f ; P += dyn_violation          (biconvex.cpp:98-99)
-            double v2 = 0;
+            double v2 = 0;   // the dynamics violation is accumulated in fp64 whatever R is
             {
-                double xn[9], w[9];
+                R xn[9], w[9];
                 UNROLL for (int l = 0; l < 9; ++l) xn[l] = from_next(fin[l]);
                 UNROLL for (int l = 0; l < 9; ++l) w[l] = fin[l] - xn[l];
                 UNROLL for (int k = 0; k < 3; ++k) w[k] += dt * xn[3 + k];
@@ -506,11 +523,11 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
                 w[7] += SZ * fin[0] - SX * fin[2];
                 w[8] += SX * fin[1] - SY * fin[0];
                 UNROLL for (int l = 0; l < 9; ++l) {
-                    const double d = rvalid ? (w[l] - bf[l]) : 0.0;
-                    const double di = l0 ? (fin[l] - a.x_init[pb * 9 + l]) : 0.0;
+                    const R d = rvalid ? (w[l] - bf[l]) : R(0);
+                    const R di = l0 ? (fin[l] - (R)a.x_init[pb * 9 + l]) : R(0);
                     if (alive && rvalid) Pg[l] += d;
                     if (alive && l0) PIg[l] += di;
-                    v2 += d * d + di * di;
+                    v2 += (double)d * (double)d + (double)di * (double)di;
                 }
             }
             v2 = seg_sum<LPP>(v2);
@@ -526,15 +543,15 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
     }
 
     // ---- results: one pass from LDS to the output blocks
-    if (kvalid) { UNROLL for (int l = 0; l < 9; ++l) Xout[l] = Xg[l]; }
+    if (kvalid) { UNROLL for (int l = 0; l < 9; ++l) Xout[l] = (double)Xg[l]; }
     if (rvalid) {
-        UNROLL for (int j = 0; j < NF; ++j) Fout[j] = Fg[j];
-        UNROLL for (int l = 0; l < 9; ++l) Pout[l] = Pg[l];
+        UNROLL for (int j = 0; j < NF; ++j) Fout[j] = (double)Fg[j];
+        UNROLL for (int l = 0; l < 9; ++l) Pout[l] = (double)Pg[l];
     }
-    if (l0) { UNROLL for (int l = 0; l < 9; ++l) PIout[l] = PIg[l]; }
+    if (l0) { UNROLL for (int l = 0; l < 9; ++l) PIout[l] = (double)PIg[l]; }
     if (l0) {
-        a.L_x[pb] = L_x;
-        a.L_f[pb] = L_f;
+        a.L_x[pb] = (double)L_x;
+        a.L_f[pb] = (double)L_f;
         if (a.dyn_viol) a.dyn_viol[pb] = last_viol;
         if (a.stats) {
             int *s = a.stats + pb * kStats;
@@ -554,26 +571,31 @@ __global__ __launch_bounds__(64) void lane_selftest_kernel(const double *in, dou
     out[320 + i] = (double)__popcll(__ballot(v > 0.0));
 }
 
-template <int LPP, bool RAW, bool HASQF>
+template <typename R, int LPP, bool RAW, bool HASQF>
 hipError_t launch(const BatchArgs &a, hipStream_t stream) {
     const int per_wave = 64 / LPP;
     const unsigned grid = (unsigned)((a.B + per_wave - 1) / per_wave);
     const size_t nstate = 2 * 9 * (size_t)(a.H + 1) + 12 * (size_t)a.H;   // X, P, F of one problem
-    const size_t lds = sizeof(double) * ((((size_t)a.c.maxit + 1) & ~(size_t)1) + per_wave * nstate);
-    hipLaunchKernelGGL((biconvex_admm_kernel<LPP, 4, RAW, HASQF>), dim3(grid), dim3(64), lds, stream, a);
+    const size_t lds = sizeof(R) * ((((size_t)a.c.maxit + 1) & ~(size_t)1) + per_wave * nstate);
+    hipLaunchKernelGGL((biconvex_admm_kernel<R, LPP, 4, RAW, HASQF>), dim3(grid), dim3(64), lds, stream, a);
     return hipGetLastError();
 }
 
 template <int LPP>
 hipError_t launch_lpp(const BatchArgs &a, hipStream_t stream) {
-    if (!a.raw) return launch<LPP, false, false>(a, stream);
-    return a.qf ? launch<LPP, true, true>(a, stream) : launch<LPP, true, false>(a, stream);
+    if (a.precision == 1) {   // fp32 arithmetic: harness form only
+        if (a.raw) return hipErrorInvalidValue;
+        return launch<float, LPP, false, false>(a, stream);
+    }
+    if (!a.raw) return launch<double, LPP, false, false>(a, stream);
+    return a.qf ? launch<double, LPP, true, true>(a, stream) : launch<double, LPP, true, false>(a, stream);
 }
 
 }  // namespace
 
 hipError_t launch_biconvex_admm(const BatchArgs &a, int n_eff, hipStream_t stream) {
-    if (n_eff != 4 || a.H < 1 || a.H + 1 > kMaxKnots || a.B < 0) return hipErrorInvalidValue;
+    if (n_eff != 4 || a.H < 1 || a.H + 1 > kMaxKnots || a.B < 0 || (a.precision != 0 && a.precision != 1))
+        return hipErrorInvalidValue;
     if (a.B == 0) return hipSuccess;
     if (a.c.maxit > kMaxFistaIters) return hipErrorInvalidValue;
     const int k = a.H + 1;
@@ -590,7 +612,7 @@ hipError_t launch_lane_selftest(const double *in, double *out, hipStream_t strea
 const char *biconvex_kernel_name(int H, int raw) {
     (void)raw;
     const int k = H + 1;
-    return k <= 16 ? "biconvex_admm_kernel<16" : (k <= 32 ? "biconvex_admm_kernel<32" : "biconvex_admm_kernel<64");
+    return k <= 16 ? "biconvex_admm_kernel<double, 16" : (k <= 32 ? "biconvex_admm_kernel<double, 32" : "biconvex_admm_kernel<double, 64");
 }
 
 }  // namespace bunmpc

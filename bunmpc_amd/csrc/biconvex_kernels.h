@@ -36,6 +36,7 @@ struct SolverConsts {
 //                   X retries, status (0 ok, 2 NaN)}
 struct BatchArgs {
     int B, H, raw, cold_start;
+    int precision;   // 0: fp64 arithmetic; 1: fp32 iterates with fp64 decisions (harness form only)
     double L0_x, L0_f;
     SolverConsts c;
     const double *cnt_plan, *dt, *x_init;

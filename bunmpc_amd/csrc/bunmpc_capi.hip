@@ -51,7 +51,7 @@ struct DevBuf {
 bunmpc::BatchArgs to_args(const bmpc_batch_t &d) {
     bunmpc::BatchArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.B = d.B; a.H = d.n_col; a.raw = d.raw; a.cold_start = d.cold_start;
+    a.B = d.B; a.H = d.n_col; a.raw = d.raw; a.cold_start = d.cold_start; a.precision = d.precision;
     a.L0_x = BMPC_L0_X; a.L0_f = BMPC_L0_F;
     a.c.m = d.m; a.c.rho = d.rho; a.c.mu = d.mu; a.c.beta = d.beta;
     a.c.tol = d.tol; a.c.exit_tol = d.exit_tol; a.c.maxit = d.maxit; a.c.num_iters = d.num_iters;
@@ -73,6 +73,8 @@ int check_batch(const bmpc_batch_t *d) {
         return fail(BMPC_BAD_ARG, "n_col + 1 > 64 knots is not supported by the one-knot-per-lane kernel");
     if (d->num_iters < 0 || d->maxit < 0) return fail(BMPC_BAD_ARG, "negative iteration cap");
     if (d->maxit > bunmpc::kMaxFistaIters) return fail(BMPC_BAD_ARG, "maxit > 8192 is not supported");
+    if (d->precision != 0 && d->precision != 1) return fail(BMPC_BAD_ARG, "precision must be 0 (fp64) or 1 (fp32)");
+    if (d->precision == 1 && d->raw) return fail(BMPC_BAD_ARG, "fp32 arithmetic is built for the harness form only");
     if (!d->cnt_plan || !d->dt || !d->x_init || !d->X || !d->F || !d->P || !d->L_x || !d->L_f)
         return fail(BMPC_BAD_ARG, "missing required array");
     if (d->raw) {

@@ -117,7 +117,9 @@ typedef struct {
     int num_iters, maxit;
     int cold_start;   /* 1: ignore X/F/P/L_x/L_f on entry and start as KinoDynMP::set_warm_starts does
                          (kino_dyn.cpp:83-99): X = tile(x_init), F = 0, P = 0, L = BMPC_L0_X / BMPC_L0_F */
-    int reserved_;
+    int precision;    /* 0: fp64 arithmetic (reference behaviour).  1: fp32 iterates / operators / projections with
+                         every accept / exit decision and the dynamics violation reduced in fp64; harness form
+                         only; arrays stay fp64 in memory (BASELINE config 3) */
     double m, rho, mu, beta, tol, exit_tol;
     const double *cnt_plan, *dt, *x_init;
     const double *W_X, *W_X_ter, *W_F, *bounds, *X_nom, *X_ter;
