@@ -169,9 +169,11 @@ def lib():
     global _lib
     if _lib is None:
         _preload_hip_runtime()
-        path = _build.LIB
-        if not os.path.exists(path) or (_build.is_stale() and os.path.exists(_build.HIPCC)):
-            path = _build.build()
+        path = os.environ.get("BUNMPC_LIB")     # side-by-side experiment builds (bunmpc_amd/build.py)
+        if not path:
+            path = _build.LIB
+            if not os.path.exists(path) or (_build.is_stale() and os.path.exists(_build.HIPCC)):
+                path = _build.build()
         handle = C.CDLL(path)
         for name, (res, args) in _SIGS.items():
             fn = getattr(handle, name)  # AttributeError if the library lacks a declared symbol

@@ -1,19 +1,26 @@
 """Builds libbunmpc_hip.so (gfx950 kernels + C-ABI) in-tree with hipcc.
 
 hipcc cross-compiles without a GPU; the built .so is git-ignored but travels with
-the working tree to the GPU box."""
+the working tree to the GPU box.  Sources are compiled to objects one by one (cached under
+csrc/_obj, keyed by the flags) and linked, so touching one kernel file recompiles only that file.
+
+    python -m bunmpc_amd.build [--force] [--usage]
+Environment: HIPCC, BUNMPC_EXTRA_FLAGS (extra compile flags, e.g. -DBWD_PROFILE), BUNMPC_LIB_OUT
+(output path, for side-by-side experiment builds; load it with BUNMPC_LIB=<path>)."""
+import hashlib
 import os
 import subprocess
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
 SOURCES = ["biconvex_admm.hip", "bunmpc_capi.hip", "ik_ddp.hip", "bunmpc_ik_capi.hip"]
-HEADERS = [os.path.join(CSRC, "biconvex_kernels.h"), os.path.join(CSRC, "ik_types.h"), os.path.join(CSRC, "rbd_device.h"),
-           os.path.join(os.path.dirname(_HERE), "include", "bunmpc.h")]
+HEADERS = [os.path.join(CSRC, h) for h in ("biconvex_kernels.h", "ik_types.h", "rbd_device.h", "rbd_quad.h")] + \
+          [os.path.join(os.path.dirname(_HERE), "include", "bunmpc.h")]
 LIB = os.path.join(_HERE, "libbunmpc_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
 def is_stale():
@@ -25,18 +32,35 @@ def is_stale():
 
 
 def build(force=False, verbose=False, extra_flags=()):
-    if not force and not is_stale():
+    out = os.environ.get("BUNMPC_LIB_OUT", LIB)
+    if not force and out == LIB and not is_stale():
         return LIB
     if not os.path.exists(HIPCC):
-        raise RuntimeError("hipcc not found at %s: cannot build %s" % (HIPCC, LIB))
-    cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+        raise RuntimeError("hipcc not found at %s: cannot build %s" % (HIPCC, out))
+    flags = FLAGS + os.environ.get("BUNMPC_EXTRA_FLAGS", "").split() + list(extra_flags)
+    key = hashlib.sha1(" ".join(flags).encode()).hexdigest()[:10]
+    os.makedirs(OBJ, exist_ok=True)
+    newest_header = max(os.path.getmtime(h) for h in HEADERS)
+    objs, procs = [], []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(OBJ, "%s.%s.o" % (src, key))
+        objs.append(op)
+        if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), newest_header):
+            cmd = [HIPCC] + flags + ["-c", sp, "-o", op]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True,
-          extra_flags=["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else [])
-    print(LIB)
+    print(build(force="--force" in sys.argv, verbose=True,
+                extra_flags=["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else []))

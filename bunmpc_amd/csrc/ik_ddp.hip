@@ -239,19 +239,96 @@ __global__ __launch_bounds__(64) void ik_calcdiff_kernel(const IkBatchArgs a) {
 }
 
 // --------------------------------------------------------------------------- backward ---
-constexpr int LD = kNDX + 1;   // padded leading dimension of the 36-wide LDS matrices
+// One wave per problem, no cross-wave barrier.  Lane r < 36 owns ROW r of every 36x36 matrix of the
+// Riccati step in registers; LDS (14.6 KB per wave) is only the exchange medium: one transposition per
+// node, the 18x18 Cholesky factor, the gain matrix (read back by broadcast) and a few vectors.
+//
+// With the integrator's F_u = dt * F_x[:, v-columns] (F_x = [[A, dt B],[0, I]], F_u = [[dt^2 B],[dt I]]),
+// everything the step needs is a slice of  G = F_x^T V F_x :
+//     Q_xx = L_xx + G,   Q_xu = dt G[:, v],   Q_uu = L_uu + dt^2 G[v, v],   Q_u = L_u + dt (F_x^T V_x)[v]
+// and since V is symmetric, lane r computes column r of N = F_x^T V from its own row of V; one LDS
+// transposition later it holds row r of N and finishes row r of G = N F_x, again lane-locally.
+constexpr int LD = kNDX + 1;   // odd leading dimension: rows and columns of 64-bit words are both conflict-free
 constexpr int LDU = kNV + 1;
-constexpr int kBwdThreads = 256;   // four waves share one problem's Riccati step
 
-struct BackwardLds {
-    double V[kNDX * LD], M1[kNDX * LD], W[kNDX * LD];
-    double Qxu[kNDX * LDU], VFu[kNDX * LDU], Kt[kNV * LD], Quu[kNV * LDU];
-    double Vx[kNDX], Qx[kNDX], Qu[kNV], kf[kNV], fs[kNDX], A6[36], B6[36], Luu[kNV], tmp[kNDX];
-    double idg[kNV];
-    int flag;
+// value of v in lane `src` (compile-time constant), wave-uniform: two v_readlane_b32
+__device__ __forceinline__ double lane_value(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+// 1 / b to ~1 ulp: v_rcp_f64 + two Newton steps
+__device__ __forceinline__ double rcp64(double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    return fma(fma(-b, r, 1.0), r, r);
+}
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+// byte offset of a __shared__ object inside the workgroup's LDS (low half of its flat address)
+__device__ __forceinline__ unsigned lds_offset(const void *p) { return (unsigned)(unsigned long long)p; }
+// Two consecutive 18-double columns (16-byte aligned) from LDS with all 18 ds_read_b128 in flight at once.
+// The compiler's scheduler keeps every LDS read glued to its first use (one exposed latency per read);
+// issuing the batch from one asm block costs one latency per batch instead.
+__device__ __forceinline__ void lds_read_2x18(unsigned addr, double2_t (&a)[9], double2_t (&b)[9]) {
+    asm volatile(
+        "ds_read_b128 %0, %18\n\tds_read_b128 %1, %18 offset:16\n\tds_read_b128 %2, %18 offset:32\n\t"
+        "ds_read_b128 %3, %18 offset:48\n\tds_read_b128 %4, %18 offset:64\n\tds_read_b128 %5, %18 offset:80\n\t"
+        "ds_read_b128 %6, %18 offset:96\n\tds_read_b128 %7, %18 offset:112\n\tds_read_b128 %8, %18 offset:128\n\t"
+        "ds_read_b128 %9, %18 offset:144\n\tds_read_b128 %10, %18 offset:160\n\tds_read_b128 %11, %18 offset:176\n\t"
+        "ds_read_b128 %12, %18 offset:192\n\tds_read_b128 %13, %18 offset:208\n\tds_read_b128 %14, %18 offset:224\n\t"
+        "ds_read_b128 %15, %18 offset:240\n\tds_read_b128 %16, %18 offset:256\n\tds_read_b128 %17, %18 offset:272\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7]), "=&v"(a[8]),
+          "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(b[6]), "=&v"(b[7]), "=&v"(b[8])
+        : "v"(addr)
+        : "memory");
+}
+
+// 36 consecutive doubles (8-byte aligned) with the 18 ds_read2_b64 in flight together
+__device__ __forceinline__ void lds_read_row36(unsigned addr, double (&x)[kNDX]) {
+    double2_t t[18];
+    asm volatile("ds_read2_b64 %0, %18 offset0:0 offset1:1\n\tds_read2_b64 %1, %18 offset0:2 offset1:3\n\tds_read2_b64 %2, %18 offset0:4 offset1:5\n\tds_read2_b64 %3, %18 offset0:6 offset1:7\n\tds_read2_b64 %4, %18 offset0:8 offset1:9\n\tds_read2_b64 %5, %18 offset0:10 offset1:11\n\tds_read2_b64 %6, %18 offset0:12 offset1:13\n\tds_read2_b64 %7, %18 offset0:14 offset1:15\n\tds_read2_b64 %8, %18 offset0:16 offset1:17\n\tds_read2_b64 %9, %18 offset0:18 offset1:19\n\tds_read2_b64 %10, %18 offset0:20 offset1:21\n\tds_read2_b64 %11, %18 offset0:22 offset1:23\n\tds_read2_b64 %12, %18 offset0:24 offset1:25\n\tds_read2_b64 %13, %18 offset0:26 offset1:27\n\tds_read2_b64 %14, %18 offset0:28 offset1:29\n\tds_read2_b64 %15, %18 offset0:30 offset1:31\n\tds_read2_b64 %16, %18 offset0:32 offset1:33\n\tds_read2_b64 %17, %18 offset0:34 offset1:35\n\t" "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]), "=&v"(t[8]), "=&v"(t[9]), "=&v"(t[10]), "=&v"(t[11]), "=&v"(t[12]), "=&v"(t[13]), "=&v"(t[14]), "=&v"(t[15]), "=&v"(t[16]), "=&v"(t[17])
+                 : "v"(addr) : "memory");
+    UNROLL_RBD for (int i = 0; i < 18; ++i) { x[2 * i] = t[i].x; x[2 * i + 1] = t[i].y; }
+}
+// 36 doubles at stride LD (column r of the row-major staging matrix): two batches of 18 ds_read_b64
+__device__ __forceinline__ void lds_read_col36(unsigned addr, double (&x)[kNDX]) {
+    asm volatile("ds_read_b64 %0, %18 offset:0\n\tds_read_b64 %1, %18 offset:296\n\tds_read_b64 %2, %18 offset:592\n\tds_read_b64 %3, %18 offset:888\n\tds_read_b64 %4, %18 offset:1184\n\tds_read_b64 %5, %18 offset:1480\n\tds_read_b64 %6, %18 offset:1776\n\tds_read_b64 %7, %18 offset:2072\n\tds_read_b64 %8, %18 offset:2368\n\tds_read_b64 %9, %18 offset:2664\n\tds_read_b64 %10, %18 offset:2960\n\tds_read_b64 %11, %18 offset:3256\n\tds_read_b64 %12, %18 offset:3552\n\tds_read_b64 %13, %18 offset:3848\n\tds_read_b64 %14, %18 offset:4144\n\tds_read_b64 %15, %18 offset:4440\n\tds_read_b64 %16, %18 offset:4736\n\tds_read_b64 %17, %18 offset:5032\n\t" "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]), "=&v"(x[8]), "=&v"(x[9]), "=&v"(x[10]), "=&v"(x[11]), "=&v"(x[12]), "=&v"(x[13]), "=&v"(x[14]), "=&v"(x[15]), "=&v"(x[16]), "=&v"(x[17])
+                 : "v"(addr) : "memory");
+    asm volatile("ds_read_b64 %0, %18 offset:5328\n\tds_read_b64 %1, %18 offset:5624\n\tds_read_b64 %2, %18 offset:5920\n\tds_read_b64 %3, %18 offset:6216\n\tds_read_b64 %4, %18 offset:6512\n\tds_read_b64 %5, %18 offset:6808\n\tds_read_b64 %6, %18 offset:7104\n\tds_read_b64 %7, %18 offset:7400\n\tds_read_b64 %8, %18 offset:7696\n\tds_read_b64 %9, %18 offset:7992\n\tds_read_b64 %10, %18 offset:8288\n\tds_read_b64 %11, %18 offset:8584\n\tds_read_b64 %12, %18 offset:8880\n\tds_read_b64 %13, %18 offset:9176\n\tds_read_b64 %14, %18 offset:9472\n\tds_read_b64 %15, %18 offset:9768\n\tds_read_b64 %16, %18 offset:10064\n\tds_read_b64 %17, %18 offset:10360\n\t" "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(x[18]), "=&v"(x[19]), "=&v"(x[20]), "=&v"(x[21]), "=&v"(x[22]), "=&v"(x[23]), "=&v"(x[24]), "=&v"(x[25]), "=&v"(x[26]), "=&v"(x[27]), "=&v"(x[28]), "=&v"(x[29]), "=&v"(x[30]), "=&v"(x[31]), "=&v"(x[32]), "=&v"(x[33]), "=&v"(x[34]), "=&v"(x[35])
+                 : "v"(addr) : "memory");
+}
+
+struct alignas(16) BackwardLds {
+    double N[kNDX * LD];       // row-major staging: N = F_x^T V for the transposition, later Q_xx -> V_xx rows
+    double Kt[kNDX * kNV];     // K^T: column j of K contiguous at Kt[18 j], read back by broadcast
+    double A6[36], B6[36];
+    double Vx[kNDX], fs[kNDX];
 };
 
-__global__ __launch_bounds__(kBwdThreads) void ik_backward_kernel(const IkBatchArgs a) {
+// x <- F_x^T x for a 36-vector held by one lane, in place: only x[0..5] feed more than one output.
+// A6 / B6 (row-major 6x6) are wave-uniform and come from LDS in one batch each.
+__device__ __forceinline__ void apply_FxT(double (&x)[kNDX], unsigned a6_addr, unsigned b6_addr, double dt) {
+    double t6[6], blk[36];
+    UNROLL_RBD for (int c = 0; c < 6; ++c) t6[c] = x[c];
+    lds_read_row36(a6_addr, blk);
+    UNROLL_RBD for (int j = 0; j < 6; ++j) {
+        double v = 0.0;
+        UNROLL_RBD for (int c = 0; c < 6; ++c) v += blk[6 * c + j] * t6[c];
+        x[j] = v;
+    }
+    lds_read_row36(b6_addr, blk);
+    UNROLL_RBD for (int k = 0; k < 6; ++k) {
+        double v = 0.0;
+        UNROLL_RBD for (int c = 0; c < 6; ++c) v += blk[6 * c + k] * t6[c];
+        x[kNV + k] = dt * v + x[kNV + k];
+    }
+    UNROLL_RBD for (int k = 6; k < kNV; ++k) x[kNV + k] = dt * x[k] + x[kNV + k];
+}
+
+__global__ __launch_bounds__(64, 2) void ik_backward_kernel(const IkBatchArgs a) {
     __shared__ BackwardLds s;
     const long b = blockIdx.x;
     const int lane = threadIdx.x;
@@ -276,180 +353,170 @@ __global__ __launch_bounds__(kBwdThreads) void ik_backward_kernel(const IkBatchA
                 state_diff<false>(xa, xb, d, nullptr);
                 UNROLL_RBD for (int i = 0; i < kNDX; ++i) { ws[L.fs + (long)lane * kNDX + i] = d[i]; mx = fmax(mx, fabs(d[i])); }
             }
-            if (lane == 0) s.flag = 0;
-            __syncthreads();
-            if (!(mx < 1e-16)) s.flag = 1;       // th_gaptol_
-            __syncthreads();
-            feas = s.flag == 0;
-            __syncthreads();
+            feas = !__any(!(mx < 1e-16));       // th_gaptol_
             if (lane == 0) sc[S_FEAS] = feas ? 1.0 : 0.0;
         } else if (!wasfeas) {
-            for (long i = lane; i < (long)(T + 1) * kNDX; i += kBwdThreads) ws[L.fs + i] = 0.0;
+            for (long i = lane; i < (long)(T + 1) * kNDX; i += 64) ws[L.fs + i] = 0.0;
         } else {
             if (lane <= T) ws[L.fs + (long)lane * kNDX] = 0.0;   // the parked node costs
         }
         __syncthreads();
     }
 
+    const bool row = lane < kNDX;                  // owns row `lane` of the 36x36 matrices
+    const int r = row ? lane : 0;
+    const bool ul = lane >= kNV && lane < kNDX;    // owns control q = lane - 18 (rows 18..35 are the v-rows)
+    const int uq = ul ? lane - kNV : 0;
+    const unsigned row_addr = lds_offset(s.N + r * LD), col_addr = lds_offset(s.N + r);
+    const unsigned a6_addr = lds_offset(s.A6), b6_addr = lds_offset(s.B6), fs_addr = lds_offset(s.fs);
     double xreg = sc[S_XREG];
+    double d1, d2, st;
+#ifdef BWD_PROFILE
+    long long pc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pt0;
+#define PSTAMP(k) { const long long now_ = __builtin_readcyclecounter(); pc[k] += now_ - pt0; pt0 = now_; }
+// stamp that cannot be passed by the computation of x (nor x's consumers hoisted above it)
+#define PSTAMPV(k, x) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(x) :: "memory"); PSTAMP(k) asm volatile("" : "+v"(x) :: "memory"); }
+#else
+#define PSTAMP(k)
+#define PSTAMPV(k, x)
+#endif
     for (;;) {   // computeDirection with regularisation retries (solver-ddp.cpp solve())
-        if (lane == 0) s.flag = 0;
-        for (int e = lane; e < kNDX * kNDX; e += kBwdThreads) {
-            const int i = e / kNDX, j = e % kNDX;
-            s.V[i * LD + j] = ws[L.Lxx + (long)T * kNDX * kNDX + e] + (i == j ? xreg : 0.0);
+        bool bad = false;
+        d1 = 0.0; d2 = 0.0; st = 0.0;
+        double m[kNDX];   // the one 36-wide register row: V -> N -> G -> Q_xx -> V_xx -> V
+        {
+            const double *LT = ws + L.Lxx + (long)T * kNDX * kNDX + (long)r * kNDX;
+            UNROLL_RBD for (int j = 0; j < kNDX; ++j) m[j] = LT[j] + (j == r ? xreg : 0.0);
         }
-        if (lane < kNDX) { s.Vx[lane] = ws[L.Lx + (long)T * kNDX + lane]; s.fs[lane] = ws[L.fs + (long)T * kNDX + lane]; }
-        __syncthreads();
-        if (!feas && lane < kNDX) {
-            double acc = 0.0;
-            for (int j = 0; j < kNDX; ++j) acc += s.V[lane * LD + j] * s.fs[j];
-            s.tmp[lane] = s.Vx[lane] + acc;
+        double vx = row ? ws[L.Lx + (long)T * kNDX + r] : 0.0;
+        if (!feas) {
+            if (row) s.fs[r] = ws[L.fs + (long)T * kNDX + r];
+            __syncthreads();
+            double acc = 0.0, fsv[kNDX];
+            lds_read_row36(fs_addr, fsv);
+            UNROLL_RBD for (int j = 0; j < kNDX; ++j) acc += m[j] * fsv[j];
+            vx += acc;
+            __syncthreads();
         }
-        __syncthreads();
-        if (!feas && lane < kNDX) s.Vx[lane] = s.tmp[lane];
-        __syncthreads();
 
         for (int t = T - 1; t >= 0; --t) {
             const double dt = a.dt[b * T + t];
-            const double dt2 = dt * dt;
+#ifdef BWD_PROFILE
+            pt0 = __builtin_readcyclecounter();
+#endif
             if (lane < 36) { s.A6[lane] = ws[L.A6 + (long)t * 36 + lane]; s.B6[lane] = ws[L.B6 + (long)t * 36 + lane]; }
-            if (lane < kNV) s.Luu[lane] = ws[L.Luu + (long)t * kNV + lane];
-            if (lane < kNDX) s.fs[lane] = ws[L.fs + (long)t * kNDX + lane];
-            for (int e = lane; e < kNDX * kNDX; e += kBwdThreads) s.W[(e / kNDX) * LD + e % kNDX] = ws[L.Lxx + (long)t * kNDX * kNDX + e];
+            if (row) { s.Vx[r] = vx; s.fs[r] = ws[L.fs + (long)t * kNDX + r]; }
             __syncthreads();
-            // M1 = Fx^T V
-            for (int e = lane; e < kNDX * kNDX; e += kBwdThreads) {
-                const int i = e / kNDX, j = e % kNDX;
-                double v;
-                if (i < 6) { v = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) v += s.A6[6 * c + i] * s.V[c * LD + j]; }
-                else if (i < kNV) v = s.V[i * LD + j];
-                else if (i < kNV + 6) { v = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) v += s.B6[6 * c + (i - kNV)] * s.V[c * LD + j]; v = dt * v + s.V[i * LD + j]; }
-                else v = dt * s.V[(i - kNV) * LD + j] + s.V[i * LD + j];
-                s.M1[i * LD + j] = v;
-            }
-            // Qx = Lx + Fx^T Vx ; Qu = Lu + Fu^T Vx
-            if (lane < kNDX) {
-                const int i = lane;
-                double v;
-                if (i < 6) { v = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) v += s.A6[6 * c + i] * s.Vx[c]; }
-                else if (i < kNV) v = s.Vx[i];
-                else if (i < kNV + 6) { v = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) v += s.B6[6 * c + (i - kNV)] * s.Vx[c]; v = dt * v + s.Vx[i]; }
-                else v = dt * s.Vx[i - kNV] + s.Vx[i];
-                s.Qx[i] = ws[L.Lx + (long)t * kNDX + i] + v;
-            }
-            if (lane < kNV) {
-                const int q = lane;
-                double v;
-                if (q < 6) { v = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) v += s.B6[6 * c + q] * s.Vx[c]; } else v = s.Vx[q];
-                s.Qu[q] = ws[L.Lu + (long)t * kNV + q] + dt2 * v + dt * s.Vx[kNV + q];
-            }
+            PSTAMPV(0, m[0])
+            apply_FxT(m, a6_addr, b6_addr, dt);                  // column r of N = F_x^T V
+            if (row) { UNROLL_RBD for (int i = 0; i < kNDX; ++i) s.N[i * LD + r] = m[i]; }
             __syncthreads();
-            // W = Lxx + M1 Fx ; Qxu = M1 Fu ; VFu = V Fu
-            for (int e = lane; e < kNDX * kNDX; e += kBwdThreads) {
-                const int i = e / kNDX, j = e % kNDX;
-                double v;
-                if (j < 6) { v = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) v += s.M1[i * LD + c] * s.A6[6 * c + j]; }
-                else if (j < kNV) v = s.M1[i * LD + j];
-                else if (j < kNV + 6) { v = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) v += s.M1[i * LD + c] * s.B6[6 * c + (j - kNV)]; v = dt * v + s.M1[i * LD + j]; }
-                else v = dt * s.M1[i * LD + (j - kNV)] + s.M1[i * LD + j];
-                s.W[i * LD + j] += v;
+            PSTAMPV(1, m[0])
+            lds_read_row36(row_addr, m);                         // row r of N
+            apply_FxT(m, a6_addr, b6_addr, dt);                  // row r of G = N F_x
+            PSTAMPV(2, m[35])
+            // Q_x = L_x + F_x^T V_x ;  Q_u = L_u + dt (F_x^T V_x)[v]
+            double fvx;
+            if (r < 6) { fvx = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) fvx += s.A6[6 * c + r] * s.Vx[c]; }
+            else if (r < kNV) fvx = s.Vx[r];
+            else if (r < kNV + 6) { fvx = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) fvx += s.B6[6 * c + (r - kNV)] * s.Vx[c]; fvx = dt * fvx + s.Vx[r]; }
+            else fvx = dt * s.Vx[r - kNV] + s.Vx[r];
+            const double qx = (row ? ws[L.Lx + (long)t * kNDX + r] : 0.0) + fvx;
+            const double qu = ul ? ws[L.Lu + (long)t * kNV + uq] + dt * fvx : 0.0;   // Q_u[q] on lane 18 + q
+            // Q_xu row; Q_uu row p on lane 18 + p (without its L_uu + reg diagonal term, kept in dgv); Q_xx row -> LDS
+            double qxu[kNV], al[kNV];
+            UNROLL_RBD for (int q = 0; q < kNV; ++q) { qxu[q] = dt * m[kNV + q]; al[q] = dt * qxu[q]; }
+            const double dgv = ul ? ws[L.Luu + (long)t * kNV + uq] + xreg : 0.0;
+            {
+                const double *Lr = ws + L.Lxx + (long)t * kNDX * kNDX + (long)r * kNDX;
+                if (row) { UNROLL_RBD for (int j = 0; j < kNDX; ++j) s.N[r * LD + j] = m[j] + Lr[j]; }
             }
-            for (int e = lane; e < kNDX * kNV; e += kBwdThreads) {
-                const int i = e / kNV, q = e % kNV;
-                double v1, v2;
-                if (q < 6) {
-                    v1 = 0.0; v2 = 0.0;
-                    UNROLL_RBD for (int c = 0; c < 6; ++c) { v1 += s.M1[i * LD + c] * s.B6[6 * c + q]; v2 += s.V[i * LD + c] * s.B6[6 * c + q]; }
-                } else { v1 = s.M1[i * LD + q]; v2 = s.V[i * LD + q]; }
-                s.Qxu[i * LDU + q] = dt2 * v1 + dt * s.M1[i * LD + kNV + q];
-                s.VFu[i * LDU + q] = dt2 * v2 + dt * s.V[i * LD + kNV + q];
+            PSTAMPV(3, al[17])
+            // Cholesky Q_uu = L L^T entirely in registers: lane 18 + p owns row p, the column entries and pivots
+            // every lane needs travel by v_readlane (wave-uniform, no LDS, no waiting).  A non-positive or NaN
+            // pivot fails the pass (Eigen::LLT info != Success).
+            double idg[kNV];
+            UNROLL_RBD for (int j = 0; j < kNV; ++j) {
+                const double piv = lane_value(al[j], kNV + j) + lane_value(dgv, kNV + j);
+                if (!(piv > 0.0)) bad = true;
+                const double f = al[j] * rcp64(piv);
+                UNROLL_RBD for (int q = j + 1; q < kNV; ++q) al[q] -= f * lane_value(al[j], kNV + q);
+                idg[j] = rcp64(sqrt(piv));
+                al[j] *= idg[j];                        // L[p][j] for the rows p > j
             }
-            __syncthreads();
-            // Quu = Luu + Fu^T (V Fu) + ureg I
-            for (int e = lane; e < kNV * kNV; e += kBwdThreads) {
-                const int p = e / kNV, q = e % kNV;
-                double v;
-                if (p < 6) { v = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) v += s.B6[6 * c + p] * s.VFu[c * LDU + q]; } else v = s.VFu[p * LDU + q];
-                v = dt2 * v + dt * s.VFu[(kNV + p) * LDU + q];
-                if (p == q) v += s.Luu[p] + xreg;
-                s.Quu[p * LDU + q] = v;
-            }
-            __syncthreads();
-            // Cholesky (lower, in place); a non-positive or NaN pivot fails the pass (Eigen::LLT info != Success)
-            // (columns stay unscaled during the elimination -- one barrier per step -- and are divided by
-            //  sqrt(pivot) in a single pass afterwards)
-            for (int j = 0; j < kNV; ++j) {
-                const double piv = s.Quu[j * LDU + j];
-                if (!(piv > 0.0)) { if (lane == 0) s.flag = 1; }
-                const double ip = 1.0 / piv;
-                for (int e = lane; e < kNV * kNV; e += kBwdThreads) {
-                    const int p = e / kNV, q = e % kNV;
-                    if (q > j && p >= q) s.Quu[p * LDU + q] -= s.Quu[p * LDU + j] * s.Quu[q * LDU + j] * ip;
-                }
-                __syncthreads();
-            }
-            for (int e = lane; e < kNV * kNV; e += kBwdThreads) {
-                const int p = e / kNV, q = e % kNV;
-                if (p > q) s.Quu[p * LDU + q] /= sqrt(s.Quu[q * LDU + q]);
-            }
-            __syncthreads();
-            if (lane < kNV) { const double d = sqrt(s.Quu[lane * LDU + lane]); s.Quu[lane * LDU + lane] = d; s.idg[lane] = 1.0 / d; }
-            __syncthreads();
+            PSTAMPV(4, idg[17])
             // K = Quu^-1 Qxu^T: lane j < 36 solves for column j (18 unknowns in registers); lane 36: k = Quu^-1 Qu
-            if (lane <= kNDX) {
-                double y[kNV];
-                UNROLL_RBD for (int p = 0; p < kNV; ++p) {
-                    double v = lane < kNDX ? s.Qxu[lane * LDU + p] : s.Qu[p];
-                    UNROLL_RBD for (int q = 0; q < p; ++q) v -= s.Quu[p * LDU + q] * y[q];
-                    y[p] = v * s.idg[p];
+            double y[kNV], quv[kNV];
+            UNROLL_RBD for (int p = 0; p < kNV; ++p) quv[p] = lane_value(qu, kNV + p);
+            UNROLL_RBD for (int p = 0; p < kNV; ++p) {
+                double w = lane < kNDX ? qxu[p] : quv[p];
+                UNROLL_RBD for (int q = 0; q < p; ++q) w -= lane_value(al[q], kNV + p) * y[q];
+                y[p] = w * idg[p];
+            }
+            // expectedImprovement / stoppingCriteria ingredients (lane 36): d2 = -k.Quu k = -|L^T k|^2 = -|L^-1 Qu|^2
+            UNROLL_RBD for (int p = 0; p < kNV; ++p) d2 -= y[p] * y[p];
+            UNROLL_RBD for (int p = kNV - 1; p >= 0; --p) {
+                double w = y[p];
+                UNROLL_RBD for (int q = p + 1; q < kNV; ++q) w -= lane_value(al[p], kNV + q) * y[q];
+                y[p] = w * idg[p];
+            }
+            PSTAMPV(5, y[0])
+            UNROLL_RBD for (int p = 0; p < kNV; ++p) { d1 += quv[p] * y[p]; st += quv[p] * quv[p]; }   // d1 = Qu.k, stop = |Qu|^2
+            double *Ks = s.Kt;
+            if (row) {
+                UNROLL_RBD for (int p = 0; p < kNV; ++p) { Ks[r * kNV + p] = y[p]; ws[L.K + (long)t * kNV * kNDX + (long)p * kNDX + r] = y[p]; }
+            } else if (lane == kNDX) {
+                UNROLL_RBD for (int p = 0; p < kNV; ++p) ws[L.kff + (long)t * kNV + p] = y[p];
+            }
+            // V_x = Q_x - K^T Q_u
+            {
+                double w = qx;
+                UNROLL_RBD for (int p = 0; p < kNV; ++p) w -= y[p] * quv[p];
+                vx = w;
+            }
+            __syncthreads();
+            PSTAMPV(6, vx)
+            // V_xx = Q_xx - Q_xu K, row r, in its LDS row: the column loop is a real loop (36 x 18 fused multiply-adds
+            // against broadcast reads of K^T; unrolled over all j the scheduler hoists every read and spills)
+            {
+                const unsigned kaddr = lds_offset(Ks);
+                for (int j0 = 0; j0 < kNDX; j0 += 2) {      // two columns per trip, their 18 K^T reads in flight together
+                    double2_t k0[9], k1[9];
+                    lds_read_2x18(kaddr + (unsigned)j0 * (kNV * 8), k0, k1);
+                    double w0 = s.N[r * LD + j0], w1 = s.N[r * LD + j0 + 1];
+                    UNROLL_RBD for (int p = 0; p < 9; ++p) {
+                        w0 -= qxu[2 * p] * k0[p].x; w1 -= qxu[2 * p] * k1[p].x;
+                        w0 -= qxu[2 * p + 1] * k0[p].y; w1 -= qxu[2 * p + 1] * k1[p].y;
+                    }
+                    if (row) { s.N[r * LD + j0] = w0; s.N[r * LD + j0 + 1] = w1; }
                 }
-                UNROLL_RBD for (int p = kNV - 1; p >= 0; --p) {
-                    double v = y[p];
-                    UNROLL_RBD for (int q = p + 1; q < kNV; ++q) v -= s.Quu[q * LDU + p] * y[q];
-                    y[p] = v * s.idg[p];
+            }
+            PSTAMPV(7, vx)
+            // V = (V_xx + V_xx^T)/2 + xreg I: own row and own column of the staged V_xx (xreg added to the staged diagonal)
+            if (row) s.N[r * LD + r] += xreg;
+            __syncthreads();
+            lds_read_row36(row_addr, m);
+            {
+                double col[kNDX];
+                lds_read_col36(col_addr, col);
+                UNROLL_RBD for (int j = 0; j < kNDX; ++j) {
+                    m[j] = 0.5 * (m[j] + col[j]);
+                    bad = bad || !(fabs(m[j]) < INFINITY);
                 }
-                if (lane < kNDX) { UNROLL_RBD for (int p = 0; p < kNV; ++p) s.Kt[p * LD + lane] = y[p]; }
-                else { UNROLL_RBD for (int p = 0; p < kNV; ++p) s.kf[p] = y[p]; }
             }
-            __syncthreads();
-            // Quuk = Quu k = L (L^T k)
-            if (lane < kNV) { double v = 0.0; for (int q = lane; q < kNV; ++q) v += s.Quu[q * LDU + lane] * s.kf[q]; s.tmp[lane] = v; }
-            __syncthreads();
-            if (lane < kNV) {
-                double v = 0.0;
-                for (int q = 0; q <= lane; ++q) v += s.Quu[lane * LDU + q] * s.tmp[q];
-                ws[L.Quuk + (long)t * kNV + lane] = v;
-                ws[L.kff + (long)t * kNV + lane] = s.kf[lane];
-                ws[L.Qu + (long)t * kNV + lane] = s.Qu[lane];
+            if (!feas) {
+                double acc = 0.0, fsv[kNDX];
+                lds_read_row36(fs_addr, fsv);
+                UNROLL_RBD for (int j = 0; j < kNDX; ++j) acc += m[j] * fsv[j];
+                vx += acc;
             }
-            for (int e = lane; e < kNV * kNDX; e += kBwdThreads) ws[L.K + (long)t * kNV * kNDX + e] = s.Kt[(e / kNDX) * LD + e % kNDX];
-            // Vx = Qx - K^T Qu ; Vxx = Qxx - Qxu K (into M1), then symmetrise + xreg
-            if (lane < kNDX) { double v = s.Qx[lane]; UNROLL_RBD for (int p = 0; p < kNV; ++p) v -= s.Kt[p * LD + lane] * s.Qu[p]; s.Vx[lane] = v; }
-            for (int e = lane; e < kNDX * kNDX; e += kBwdThreads) {
-                const int i = e / kNDX, j = e % kNDX;
-                double v = s.W[i * LD + j];
-                UNROLL_RBD for (int p = 0; p < kNV; ++p) v -= s.Qxu[i * LDU + p] * s.Kt[p * LD + j];
-                s.M1[i * LD + j] = v;
-            }
+            bad = bad || !(fabs(vx) < INFINITY);       // raiseIfNaN on Vx / Vxx
+            bad = __any(bad && (row || lane < kNV));
             __syncthreads();
-            bool bad = false;
-            for (int e = lane; e < kNDX * kNDX; e += kBwdThreads) {
-                const int i = e / kNDX, j = e % kNDX;
-                const double v = 0.5 * (s.M1[i * LD + j] + s.M1[j * LD + i]) + (i == j ? xreg : 0.0);
-                s.V[i * LD + j] = v;
-                bad = bad || !(fabs(v) < INFINITY);
-            }
-            __syncthreads();
-            if (!feas && lane < kNDX) { double acc = 0.0; for (int j = 0; j < kNDX; ++j) acc += s.V[lane * LD + j] * s.fs[j]; s.tmp[lane] = s.Vx[lane] + acc; }
-            __syncthreads();
-            if (!feas && lane < kNDX) s.Vx[lane] = s.tmp[lane];
-            if (lane < kNDX) bad = bad || !(fabs(s.Vx[lane]) < INFINITY);   // raiseIfNaN on Vx / Vxx
-            if (bad) s.flag = 1;
-            __syncthreads();
-            if (s.flag) break;
+            PSTAMPV(8, vx)
+            if (bad) break;
         }
-        __syncthreads();
-        if (!s.flag) break;
+        if (!bad) break;
         // increaseRegularization; give up at reg_max (solve() returns false)
         xreg = fmin(xreg * 10.0, 1e9);
         if (lane == 0) { sc[S_XREG] = xreg; sc[S_RECALC] = 0.0; }
@@ -457,18 +524,11 @@ __global__ __launch_bounds__(kBwdThreads) void ik_backward_kernel(const IkBatchA
             if (lane == 0) { sc[S_DONE] = 1.0; sc[S_STATUS] = 2.0; atomicSub(a.active, 1); }
             return;
         }
-        __syncthreads();
     }
-    // expectedImprovement / stoppingCriteria ingredients
-    double d1 = 0.0, d2 = 0.0, st = 0.0;
-    __syncthreads();
-    if (lane >= 64) return;
-    for (int e = lane; e < T * kNV; e += 64) {
-        const double qu = ws[L.Qu + e], kk = ws[L.kff + e];
-        d1 += qu * kk; d2 -= kk * ws[L.Quuk + e]; st += qu * qu;
-    }
-    for (int off = 32; off > 0; off >>= 1) { d1 += __shfl_down(d1, off); d2 += __shfl_down(d2, off); st += __shfl_down(st, off); }
-    if (lane == 0) { sc[S_D1] = d1; sc[S_D2] = d2; sc[S_STOP] = st; }
+#ifdef BWD_PROFILE
+    if (lane == 0) { for (int k = 0; k < 9; ++k) ws[L.Quuk + k] = (double)pc[k]; }   // the Quuk slot is unused by the solver
+#endif
+    if (lane == kNDX) { sc[S_D1] = d1; sc[S_D2] = d2; sc[S_STOP] = st; }   // lane 36 solved for the feed-forward terms
 }
 
 // ---------------------------------------------------------------------------- forward ---
@@ -675,7 +735,7 @@ hipError_t ik_launch_calcdiff(const IkBatchArgs &a, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t ik_launch_backward(const IkBatchArgs &a, hipStream_t st) {
-    hipLaunchKernelGGL(ik_backward_kernel, dim3(a.B), dim3(kBwdThreads), 0, st, a);
+    hipLaunchKernelGGL(ik_backward_kernel, dim3(a.B), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 hipError_t ik_launch_forward(const IkBatchArgs &a, hipStream_t st) {

@@ -1,0 +1,19 @@
+"""Cycle buckets of ik_backward_kernel (build with -DBWD_PROFILE): per-node average of
+[stage inputs, apply+transpose+apply, Cholesky, gain solve, Schur+symmetrise] for a lone problem and in a full batch."""
+import sys
+sys.path.insert(0, ".")
+import numpy as np, torch
+from bunmpc_amd import problems, urdf_model
+from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
+model = urdf_model.RobotModel.from_json(open("bunmpc_amd/robots/solo12.json").read())
+for B in (1, 4096):
+    wb = problems.make_wb_batch(model, B)
+    kb = KinoDynDeviceBatch(wb, model, num_iters=10)
+    kb.solve(); r = kb.results()
+    T = wb.ik_T    # IkLayout::make (csrc/ik_types.h) up to the Quuk slot
+    o = sum([(T + 1) * 37, T * 18, (T + 1) * 37, T * 18, (T + 1) * 36, T * 37, (T + 1) * 36, (T + 1) * 1296, T * 18, T * 18,
+             T * 36, T * 36, T * 648, T * 18, T * 18])
+    ws = kb.ws.cpu().numpy()
+    c = ws[:, o:o + 9] / wb.ik_T      # last backward pass only
+    names = "stage apply1 row+apply2 qxu+Lxx chol solve store+vx schur sym+fs".split()
+    print("B", B, "cycles/node:", " ".join("%s %d" % (n, v) for n, v in zip(names, c.mean(0))), "| sum", round(c.mean(0).sum()))
