@@ -134,7 +134,7 @@ struct CalcLds {
     double rs[kNDX], Jl[36];          // state residual and the Jlog6 block of its Jacobian
 };
 
-__global__ __launch_bounds__(64) void ik_calcdiff_kernel(const IkBatchArgs a) {
+__global__ __launch_bounds__(64, 2) void ik_calcdiff_kernel(const IkBatchArgs a) {
     __shared__ CalcLds s;
     const int nn = a.T + 1;
     const long b = blockIdx.x / nn;
