@@ -13,14 +13,15 @@
 //                       pass (rbd_quad.h), lanes 0..17 each own one velocity column (CoM Jacobian,
 //                       A_g, dh_g/dq, frame Jacobians) written to LDS, then all 64 lanes assemble
 //                       the Gauss-Newton L_x / L_xx from those rows (coalesced 10 KB store).
-//   ik_backward_kernel  one WAVE per problem: Riccati recursion with V_xx, Q_xx, Q_xu, Q_uu, K held
-//                       in LDS (~53 KB/wave), exploiting F_x = [[A, dt B],[0, I]], F_u = [[dt^2 B],[dt I]]
-//                       (A, B identity except a 6x6 free-flyer block) so F^T V F costs O(n^2);
-//                       Cholesky and triangular solves cooperative across the 64 lanes, in LDS;
-//                       regularisation retries inside the kernel.
+//   ik_backward_kernel  one WAVE per problem, matrix rows in registers (lane r = row r of V, G, Q_xx), exploiting
+//                       F_x = [[A, dt B],[0, I]], F_u = dt F_x[:, v] (A, B identity except a 6x6 free-flyer block):
+//                       G = F_x^T V F_x via one LDS transposition, Cholesky and the gain solves in registers
+//                       over v_readlane, V_xx = Q_xx - Q_xu K against broadcast LDS reads; regularisation
+//                       retries inside the kernel (details above the kernel).
 //   ik_forward_kernel   one WAVE per problem: line search 2^-k, k = 0..9 -- lanes 0..17 apply the
-//                       feedback u = u - a k - K dx, then the node cost / Euler step; acceptance,
-//                       regularisation update and stopping test as crocoddyl 1.9.0 solver-ddp.cpp.
+//                       feedback u = u - a k - K dx, the node evaluation is spread over lanes (legs, base,
+//                       state cost, control cost + Euler step); acceptance, regularisation update and
+//                       stopping test as crocoddyl 1.9.0 solver-ddp.cpp.
 // The host loops over DDP iterations and stops when the device-side active counter reaches zero.
 #include "ik_types.h"
 #include "rbd_quad.h"
