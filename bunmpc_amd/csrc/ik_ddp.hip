@@ -25,11 +25,22 @@
 // The host loops over DDP iterations and stops when the device-side active counter reaches zero.
 #include "ik_types.h"
 #include "rbd_quad.h"
+#include "lds_batch.h"
 
 namespace bunmpc {
 namespace {
 
 using namespace rbd;
+
+// -DBWD_PROFILE: cycle stamps inside the kernels (tools/bwd_profile.py reads them back); PSTAMPV cannot be passed
+// by the computation of x
+#ifdef BWD_PROFILE
+#define PSTAMP(k) { const long long now_ = __builtin_readcyclecounter(); pc[k] += now_ - pt0; pt0 = now_; }
+#define PSTAMPV(k, x) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(x) :: "memory"); PSTAMP(k) asm volatile("" : "+v"(x) :: "memory"); }
+#else
+#define PSTAMP(k)
+#define PSTAMPV(k, x)
+#endif
 
 struct NodeTasks {
     const double *t;  // kNodeTaskDoubles
@@ -126,54 +137,74 @@ __global__ void ik_init_kernel(const IkBatchArgs a) {
 }
 
 // --------------------------------------------------------------------------- calcDiff ---
-struct CalcLds {
+// Residual rows of one node, stored by COLUMN of the state tangent: Jt[j] = [dh_g/dx (6) | dCoM/dq (3) |
+// frame translations (4 x 3) | pad]; the velocity half (j >= 18) carries A_g in the momentum rows only.
+constexpr int kRes = 6 + 3 + 3 * kFrameSlots;   // 21 residual rows
+constexpr int kResLd = kRes + 1;                // 22 doubles = 11 x 16 bytes per column
+
+constexpr int kParts = kLegs + 1;        // legs 0..3, base body 4
+constexpr int kPartDoubles = 16;         // Comp (m, h1[3], I[6]) + momentum about the origin (6)
+
+struct alignas(16) CalcLds {
+    double Jt[kNDX][kResLd];
+    double JlT[6][6];                 // Jlog6 block of the state residual Jacobian, transposed: JlT[i][k] = Jl[6 k + i]
+    double parts[kParts][kPartDoubles];
+    double res[kResLd];               // residuals [momentum 6 | CoM 3 | frames 12 | pad]
+    double fx[kFrameSlots][3];        // task-frame positions (written by the part that carries the frame)
+    double rs[kNDX];                  // state residual
+    double cost_kin, cost_sc;         // node cost: momentum + CoM + frames | state + control
     RobotModelDev m;
     double x[kNX], u[kNV];
-    double Rm[6][kNDX];               // centroidal momentum rows [dh/dq, A_g]
-    double Jc[3][kNV];                // CoM rows
-    double Jf[kFrameSlots][3][kNV];   // frame rows
-    double rs[kNDX], Jl[36];          // state residual and the Jlog6 block of its Jacobian
 };
 
-__global__ __launch_bounds__(64, 2) void ik_calcdiff_kernel(const IkBatchArgs a) {
+// Workgroup = two waves per (problem, node).  Wave 0: lanes 0..17 each walk their own part of the robot once (base
+// lanes the base body, joint lanes their leg), the five part sums meet in LDS, every lane finishes its column.  Wave 1,
+// meanwhile: the state residual with its Jlog6 block and the Euler step with its Jintegrate blocks (one lane; a
+// different instruction stream, so it would serialise inside wave 0).  Then both waves assemble the Gauss-Newton
+// L_x / L_xx, lane j = column j, rows split between the waves.
+__global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a) {
     __shared__ CalcLds s;
     const int nn = a.T + 1;
     const long b = blockIdx.x / nn;
-    const int t = blockIdx.x % nn, lane = threadIdx.x;
+    const int t = blockIdx.x % nn, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const IkLayout L = IkLayout::make(a.T);
     double *ws = a.ws + b * L.total;
     if (ws[L.scal + S_DONE] != 0.0 || ws[L.scal + S_RECALC] == 0.0) return;
     const bool terminal = t == a.T;
+#ifdef BWD_PROFILE
+    long long pc[6] = {0, 0, 0, 0, 0, 0}, pt0 = __builtin_readcyclecounter();
+#endif
     {
         const int *src = reinterpret_cast<const int *>(a.model);
         int *dst = reinterpret_cast<int *>(&s.m);
-        for (int i = lane; i < (int)(sizeof(RobotModelDev) / sizeof(int)); i += 64) dst[i] = src[i];
+        for (int i = threadIdx.x; i < (int)(sizeof(RobotModelDev) / sizeof(int)); i += 128) dst[i] = src[i];
     }
     const RobotModelDev &m = s.m;
     NodeTasks tk{a.tasks + (b * nn + t) * kNodeTaskDoubles};
     const double *state_w = batch_ptr(a.state_w, a.s_state_w, b), *ctrl_w = batch_ptr(a.ctrl_w, a.s_ctrl_w, b);
     const double dt = terminal ? 0.0 : a.dt[b * a.T + t];
-    if (lane < kNX) s.x[lane] = ws[L.xs + (long)t * kNX + lane];
-    if (lane < kNV) s.u[lane] = terminal ? 0.0 : ws[L.us + (long)t * kNV + lane];
+    if (threadIdx.x < kNX) s.x[threadIdx.x] = ws[L.xs + (long)t * kNX + threadIdx.x];
+    if (threadIdx.x >= 64 && lane < kNV) s.u[lane] = terminal ? 0.0 : ws[L.us + (long)t * kNV + lane];
     __syncthreads();
-    Pass1 p1; Residuals r;
-    double cost = kin_costs<true>(m, s.x, tk, p1, r);     // every lane: the same robot pass, in registers
+    PSTAMP(0)
     const double wm = tk.mom_w(), wc = tk.com_w(), wst = tk.state_w(), wu = tk.ctrl_w();
-    if (lane < kNV) {   // one velocity column per lane
-        Column c;
-        quad_column(m, s.x, p1, lane, c);
-        UNROLL_RBD for (int k = 0; k < 3; ++k) s.Jc[k][lane] = c.jc[k];
-        UNROLL_RBD for (int k = 0; k < 6; ++k) { s.Rm[k][lane] = c.dh[k]; s.Rm[k][kNV + lane] = c.ag[k]; }
-        UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) {
-            double j3[3] = {0, 0, 0};
-            if (tk.frame_w(f) != 0.0 && quad_supports(m, tk.frame_id(f), lane)) {
-                cross3(c.S + 3, p1.fx[f], j3);
-                UNROLL_RBD for (int k = 0; k < 3; ++k) j3[k] += c.S[k];
-            }
-            UNROLL_RBD for (int k = 0; k < 3; ++k) s.Jf[f][k][lane] = j3[k];
+    PartWalk pw;
+    double Rb[9], pb[3], Vb[6];
+    if (wave == 0 && lane < kNV) {
+        int fid[kFrameSlots];
+        UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) fid[f] = tk.frame_w(f) != 0.0 ? tk.frame_id(f) : -1;
+        quad_part_walk(m, s.x, fid, lane, Rb, pb, Vb, pw);
+        const bool leg_pub = lane >= 6 && (lane - 6) % kLegJoints == 0;
+        if (lane == 0 || leg_pub) {   // one publisher per part
+            double *pp = s.parts[lane == 0 ? kLegs : (lane - 6) / kLegJoints];
+            pp[0] = pw.part.m;
+            UNROLL_RBD for (int c = 0; c < 3; ++c) pp[1 + c] = pw.part.h1[c];
+            UNROLL_RBD for (int c = 0; c < 6; ++c) { pp[4 + c] = pw.part.I[c]; pp[10 + c] = pw.hpart[c]; }
+            UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
+                if (pw.fhit[f]) { UNROLL_RBD for (int c = 0; c < 3; ++c) s.fx[f][c] = pw.fx[f][c]; }
         }
-    } else if (lane == 32) {   // state residual + its Jacobian block, Euler step, node cost
-        double rs[kNDX], Jl[36];
+    } else if (wave == 1 && lane == 0) {   // state residual + its Jacobian block, Euler step, their part of the node cost
+        double rs[kNDX], Jl[36], cost = 0.0;
         if (wst != 0.0) {
             state_diff<true>(a.x_reg + b * kNX, s.x, rs, Jl);
             double acc = 0.0;
@@ -184,7 +215,7 @@ __global__ __launch_bounds__(64, 2) void ik_calcdiff_kernel(const IkBatchArgs a)
             UNROLL_RBD for (int i = 0; i < 36; ++i) Jl[i] = (i % 7 == 0) ? 1.0 : 0.0;
         }
         UNROLL_RBD for (int i = 0; i < kNDX; ++i) s.rs[i] = rs[i];
-        UNROLL_RBD for (int i = 0; i < 36; ++i) s.Jl[i] = Jl[i];
+        UNROLL_RBD for (int i = 0; i < 6; ++i) UNROLL_RBD for (int k = 0; k < 6; ++k) s.JlT[i][k] = Jl[6 * k + i];
         if (!terminal) {
             double acc = 0.0;
             UNROLL_RBD for (int i = 0; i < kNV; ++i) acc += ctrl_w[i] * s.u[i] * s.u[i];
@@ -193,50 +224,152 @@ __global__ __launch_bounds__(64, 2) void ik_calcdiff_kernel(const IkBatchArgs a)
             euler_step<true>(s.x, s.u, dt, xn, A6, B6);
             UNROLL_RBD for (int i = 0; i < kNX; ++i) ws[L.xnext + (long)t * kNX + i] = xn[i];
             UNROLL_RBD for (int i = 0; i < 36; ++i) { ws[L.A6 + (long)t * 36 + i] = A6[i]; ws[L.B6 + (long)t * 36 + i] = B6[i]; }
-            cost *= dt;
         }
-        // node costs are summed by the backward kernel: parked in the fs slot of this node
-        ws[L.fs + (long)t * kNDX] = cost;
+        s.cost_sc = cost;
     }
     __syncthreads();
+    PSTAMP(1)
+    if (wave == 0 && lane < kNV) {   // robot totals from the five parts, then this lane's column
+        Comp call; double hO[6];
+        {
+            double2_t pa[20], pb2[20];
+            lds_read_b128x20(lds_offset(s.parts), pa);
+            lds_read_b128x20(lds_offset(s.parts) + 320, pb2);
+            double tot[kPartDoubles];
+            UNROLL_RBD for (int k = 0; k < kPartDoubles; ++k) {
+                double acc = 0.0;
+                UNROLL_RBD for (int q = 0; q < kParts; ++q) {
+                    const int e = q * kPartDoubles + k;   // element index in the 80-double block
+                    const double2_t v2 = e < 40 ? pa[e >> 1] : pb2[(e - 40) >> 1];
+                    acc += (e & 1) ? v2.y : v2.x;
+                }
+                tot[k] = acc;
+            }
+            call.m = tot[0];
+            UNROLL_RBD for (int c = 0; c < 3; ++c) call.h1[c] = tot[1 + c];
+            UNROLL_RBD for (int c = 0; c < 6; ++c) { call.I[c] = tot[4 + c]; hO[c] = tot[10 + c]; }
+        }
+        const double M = call.m, iM = 1.0 / M;
+        double com[3], t3[3], hg[6];
+        UNROLL_RBD for (int c = 0; c < 3; ++c) com[c] = call.h1[c] * iM;
+        cross3(com, hO, t3);
+        UNROLL_RBD for (int c = 0; c < 3; ++c) { hg[c] = hO[c]; hg[3 + c] = hO[3 + c] - t3[c]; }
+        if (lane < 6) { pw.cs = call; UNROLL_RBD for (int c = 0; c < 6; ++c) pw.hs[c] = hO[c]; }   // base columns move the whole robot
+        Column c;
+        quad_col_finish(pw, M, com, hO, c);
+        double *cq = s.Jt[lane], *cv = s.Jt[kNV + lane];
+        UNROLL_RBD for (int k = 0; k < 6; ++k) { cq[k] = c.dh[k]; cv[k] = c.ag[k]; }
+        UNROLL_RBD for (int k = 0; k < 3; ++k) cq[6 + k] = c.jc[k];
+        UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) {
+            double j3[3] = {0, 0, 0};
+            if (tk.frame_w(f) != 0.0 && quad_supports(m, tk.frame_id(f), lane)) {
+                const double fxf[3] = {s.fx[f][0], s.fx[f][1], s.fx[f][2]};
+                cross3(c.S + 3, fxf, j3);
+                UNROLL_RBD for (int k = 0; k < 3; ++k) j3[k] += c.S[k];
+            }
+            UNROLL_RBD for (int k = 0; k < 3; ++k) cq[9 + 3 * f + k] = j3[k];
+        }
+        cq[kRes] = 0.0;
+        UNROLL_RBD for (int k = 6; k < kResLd; ++k) cv[k] = 0.0;
+        if (lane == 0) {   // residuals and their cost
+            double cost = 0.0, acc = 0.0;
+            UNROLL_RBD for (int k = 0; k < 6; ++k) { const double rr = hg[k] - tk.mom_ref()[k]; s.res[k] = rr; acc += rr * rr; }
+            cost += wm * 0.5 * acc;
+            acc = 0.0;
+            UNROLL_RBD for (int k = 0; k < 3; ++k) { const double rr = com[k] - tk.com_ref()[k]; s.res[6 + k] = rr; acc += rr * rr; }
+            cost += wc * 0.5 * acc;
+            UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) {
+                const double w = tk.frame_w(f);
+                acc = 0.0;
+                UNROLL_RBD for (int k = 0; k < 3; ++k) { const double rr = w != 0.0 ? s.fx[f][k] - tk.frame_ref(f)[k] : 0.0; s.res[9 + 3 * f + k] = rr; acc += rr * rr; }
+                cost += w * 0.5 * acc;
+            }
+            s.res[kRes] = 0.0;
+            s.cost_kin = cost;
+        }
+    }
+    __syncthreads();
+    PSTAMP(2)
     const double sc = terminal ? 1.0 : dt;
-    // L_x
-    if (lane < kNDX) {
-        const int i = lane;
-        double g = 0.0;
-        UNROLL_RBD for (int k = 0; k < 6; ++k) g += s.Rm[k][i] * r.rm[k];
-        g *= wm;
-        if (i < kNV) {
-            g += wc * (s.Jc[0][i] * r.rc[0] + s.Jc[1][i] * r.rc[1] + s.Jc[2][i] * r.rc[2]);
-            UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
-                g += tk.frame_w(f) * (s.Jf[f][0][i] * r.rf[f][0] + s.Jf[f][1][i] * r.rf[f][1] + s.Jf[f][2][i] * r.rf[f][2]);
-        }
-        if (i < 6) { double acc = 0.0; for (int k = 0; k < 6; ++k) acc += s.Jl[6 * k + i] * state_w[k] * s.rs[k]; g += wst * acc; }
-        else g += wst * state_w[i] * s.rs[i];
-        ws[L.Lx + (long)t * kNDX + i] = sc * g;
-    }
-    // L_xx (Gauss-Newton): every lane ~20 entries, rows read from LDS, coalesced store
-    double *Lxx = ws + L.Lxx + (long)t * kNDX * kNDX;
-    double fw[kFrameSlots];
-    UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) fw[f] = tk.frame_w(f);
-    for (int e = lane; e < kNDX * kNDX; e += 64) {
-        const int i = e / kNDX, j = e % kNDX;
-        double h = 0.0;
-        UNROLL_RBD for (int k = 0; k < 6; ++k) h += s.Rm[k][i] * s.Rm[k][j];
-        h *= wm;
-        if (i < kNV && j < kNV) {
-            h += wc * (s.Jc[0][i] * s.Jc[0][j] + s.Jc[1][i] * s.Jc[1][j] + s.Jc[2][i] * s.Jc[2][j]);
-            UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
-                h += fw[f] * (s.Jf[f][0][i] * s.Jf[f][0][j] + s.Jf[f][1][i] * s.Jf[f][1][j] + s.Jf[f][2][i] * s.Jf[f][2][j]);
-        }
-        if (i < 6 && j < 6) { double acc = 0.0; for (int k = 0; k < 6; ++k) acc += s.Jl[6 * k + i] * state_w[k] * s.Jl[6 * k + j]; h += wst * acc; }
-        else if (i == j) h += wst * state_w[i];
-        Lxx[e] = sc * h;
-    }
-    if (!terminal && lane < kNV) {
+    if (wave == 1 && !terminal && lane < kNV) {
         ws[L.Lu + (long)t * kNV + lane] = sc * wu * ctrl_w[lane] * s.u[lane];
         ws[L.Luu + (long)t * kNV + lane] = sc * wu * ctrl_w[lane];
     }
+    // node costs are summed by the backward kernel: parked in the fs slot of this node
+    if (threadIdx.x == 0) ws[L.fs + (long)t * kNDX] = terminal ? s.cost_kin + s.cost_sc : dt * (s.cost_kin + s.cost_sc);
+    if (lane >= kNDX) return;
+    // Gauss-Newton L_x / L_xx, lane j = column j:  L_xx[i][j] = sum_k J[k][i] w_k J[k][j]  (+ the state regularisation
+    // block), the weighted own column in registers, row i's column read back by broadcast (ds_read_b128 batches),
+    // stores coalesced across j.  Row pairs alternate between the two waves.
+    const int j = lane;
+    double jw[kRes];
+    {
+        double2_t own[11];
+        lds_read_b128x11(lds_offset(s.Jt[j]), own);
+        UNROLL_RBD for (int k = 0; k < kRes; ++k) jw[k] = (k & 1) ? own[k >> 1].y : own[k >> 1].x;
+    }
+    UNROLL_RBD for (int k = 0; k < 6; ++k) jw[k] *= wm;
+    UNROLL_RBD for (int k = 0; k < 3; ++k) jw[6 + k] *= wc;
+    UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
+        UNROLL_RBD for (int k = 0; k < 3; ++k) jw[9 + 3 * f + k] *= tk.frame_w(f);
+    const double swj = wst * state_w[j];
+    double jlw[6];     // wst * state_w[k] * Jl[k][j] for the 6x6 free-flyer block of the state residual Jacobian
+    UNROLL_RBD for (int k = 0; k < 6; ++k) jlw[k] = j < 6 ? wst * state_w[k] * s.JlT[j][k] : 0.0;
+    if (wave == 0) {   // L_x
+        double2_t rr[11];
+        lds_read_b128x11(lds_offset(s.res), rr);
+        double g = 0.0;
+        UNROLL_RBD for (int k = 0; k < kRes; ++k) g += jw[k] * ((k & 1) ? rr[k >> 1].y : rr[k >> 1].x);
+        if (j < 6) { UNROLL_RBD for (int k = 0; k < 6; ++k) g += jlw[k] * s.rs[k]; }
+        else g += swj * s.rs[j];
+        ws[L.Lx + (long)t * kNDX + j] = sc * g;
+    }
+    double *Lxx = ws + L.Lxx + (long)t * kNDX * kNDX;
+    const unsigned jt_addr = lds_offset(s.Jt), jl_addr = lds_offset(s.JlT);
+    for (int i0 = 2 * wave; i0 < 6; i0 += 4) {    // rows of the free-flyer block: all 21 residual rows + the Jlog6 block
+        double2_t ri[22], jl[3], jl2[3];
+        lds_read_b128x22(jt_addr + (unsigned)i0 * (kResLd * 8), ri);
+        lds_read_b128x3(jl_addr + (unsigned)i0 * 48, jl);
+        lds_read_b128x3(jl_addr + (unsigned)(i0 + 1) * 48, jl2);
+        double h0 = 0.0, h1 = 0.0;
+        UNROLL_RBD for (int k = 0; k < kRes; ++k) {
+            h0 += jw[k] * ((k & 1) ? ri[k >> 1].y : ri[k >> 1].x);
+            h1 += jw[k] * ((k & 1) ? ri[11 + (k >> 1)].y : ri[11 + (k >> 1)].x);
+        }
+        UNROLL_RBD for (int k = 0; k < 6; ++k) {
+            h0 += jlw[k] * ((k & 1) ? jl[k >> 1].y : jl[k >> 1].x);
+            h1 += jlw[k] * ((k & 1) ? jl2[k >> 1].y : jl2[k >> 1].x);
+        }
+        Lxx[(long)i0 * kNDX + j] = sc * h0;
+        Lxx[(long)(i0 + 1) * kNDX + j] = sc * h1;
+    }
+    for (int i0 = 6 + 2 * ((wave + 1) & 1); i0 < kNV; i0 += 4) {   // joint rows
+        double2_t ri[22];
+        lds_read_b128x22(jt_addr + (unsigned)i0 * (kResLd * 8), ri);
+        double h0 = 0.0, h1 = 0.0;
+        UNROLL_RBD for (int k = 0; k < kRes; ++k) {
+            h0 += jw[k] * ((k & 1) ? ri[k >> 1].y : ri[k >> 1].x);
+            h1 += jw[k] * ((k & 1) ? ri[11 + (k >> 1)].y : ri[11 + (k >> 1)].x);
+        }
+        Lxx[(long)i0 * kNDX + j] = sc * (h0 + (i0 == j ? swj : 0.0));
+        Lxx[(long)(i0 + 1) * kNDX + j] = sc * (h1 + (i0 + 1 == j ? swj : 0.0));
+    }
+    for (int i0 = kNV + 2 * wave; i0 < kNDX; i0 += 4) {      // velocity rows: only the 6 momentum rows are non-zero
+        double2_t ra[3], rb[3];
+        lds_read_b128x3(jt_addr + (unsigned)i0 * (kResLd * 8), ra);
+        lds_read_b128x3(jt_addr + (unsigned)(i0 + 1) * (kResLd * 8), rb);
+        double h0 = 0.0, h1 = 0.0;
+        UNROLL_RBD for (int k = 0; k < 6; ++k) {
+            h0 += jw[k] * ((k & 1) ? ra[k >> 1].y : ra[k >> 1].x);
+            h1 += jw[k] * ((k & 1) ? rb[k >> 1].y : rb[k >> 1].x);
+        }
+        Lxx[(long)i0 * kNDX + j] = sc * (h0 + (i0 == j ? swj : 0.0));
+        Lxx[(long)(i0 + 1) * kNDX + j] = sc * (h1 + (i0 + 1 == j ? swj : 0.0));
+    }
+#ifdef BWD_PROFILE
+    PSTAMP(3)
+    if (threadIdx.x == 0 && t == 0) { for (int k = 0; k < 4; ++k) ws[L.Qu + k] = (double)pc[k]; }   // the Qu slot is unused by the solver
+#endif
 }
 
 // --------------------------------------------------------------------------- backward ---
@@ -261,45 +394,6 @@ __device__ __forceinline__ double rcp64(double b) {
     double r = __builtin_amdgcn_rcp(b);
     r = fma(fma(-b, r, 1.0), r, r);
     return fma(fma(-b, r, 1.0), r, r);
-}
-
-typedef double double2_t __attribute__((ext_vector_type(2)));
-// byte offset of a __shared__ object inside the workgroup's LDS (low half of its flat address)
-__device__ __forceinline__ unsigned lds_offset(const void *p) { return (unsigned)(unsigned long long)p; }
-// Two consecutive 18-double columns (16-byte aligned) from LDS with all 18 ds_read_b128 in flight at once.
-// The compiler's scheduler keeps every LDS read glued to its first use (one exposed latency per read);
-// issuing the batch from one asm block costs one latency per batch instead.
-__device__ __forceinline__ void lds_read_2x18(unsigned addr, double2_t (&a)[9], double2_t (&b)[9]) {
-    asm volatile(
-        "ds_read_b128 %0, %18\n\tds_read_b128 %1, %18 offset:16\n\tds_read_b128 %2, %18 offset:32\n\t"
-        "ds_read_b128 %3, %18 offset:48\n\tds_read_b128 %4, %18 offset:64\n\tds_read_b128 %5, %18 offset:80\n\t"
-        "ds_read_b128 %6, %18 offset:96\n\tds_read_b128 %7, %18 offset:112\n\tds_read_b128 %8, %18 offset:128\n\t"
-        "ds_read_b128 %9, %18 offset:144\n\tds_read_b128 %10, %18 offset:160\n\tds_read_b128 %11, %18 offset:176\n\t"
-        "ds_read_b128 %12, %18 offset:192\n\tds_read_b128 %13, %18 offset:208\n\tds_read_b128 %14, %18 offset:224\n\t"
-        "ds_read_b128 %15, %18 offset:240\n\tds_read_b128 %16, %18 offset:256\n\tds_read_b128 %17, %18 offset:272\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7]), "=&v"(a[8]),
-          "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(b[6]), "=&v"(b[7]), "=&v"(b[8])
-        : "v"(addr)
-        : "memory");
-}
-
-// 36 consecutive doubles (8-byte aligned) with the 18 ds_read2_b64 in flight together
-__device__ __forceinline__ void lds_read_row36(unsigned addr, double (&x)[kNDX]) {
-    double2_t t[18];
-    asm volatile("ds_read2_b64 %0, %18 offset0:0 offset1:1\n\tds_read2_b64 %1, %18 offset0:2 offset1:3\n\tds_read2_b64 %2, %18 offset0:4 offset1:5\n\tds_read2_b64 %3, %18 offset0:6 offset1:7\n\tds_read2_b64 %4, %18 offset0:8 offset1:9\n\tds_read2_b64 %5, %18 offset0:10 offset1:11\n\tds_read2_b64 %6, %18 offset0:12 offset1:13\n\tds_read2_b64 %7, %18 offset0:14 offset1:15\n\tds_read2_b64 %8, %18 offset0:16 offset1:17\n\tds_read2_b64 %9, %18 offset0:18 offset1:19\n\tds_read2_b64 %10, %18 offset0:20 offset1:21\n\tds_read2_b64 %11, %18 offset0:22 offset1:23\n\tds_read2_b64 %12, %18 offset0:24 offset1:25\n\tds_read2_b64 %13, %18 offset0:26 offset1:27\n\tds_read2_b64 %14, %18 offset0:28 offset1:29\n\tds_read2_b64 %15, %18 offset0:30 offset1:31\n\tds_read2_b64 %16, %18 offset0:32 offset1:33\n\tds_read2_b64 %17, %18 offset0:34 offset1:35\n\t" "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]), "=&v"(t[8]), "=&v"(t[9]), "=&v"(t[10]), "=&v"(t[11]), "=&v"(t[12]), "=&v"(t[13]), "=&v"(t[14]), "=&v"(t[15]), "=&v"(t[16]), "=&v"(t[17])
-                 : "v"(addr) : "memory");
-    UNROLL_RBD for (int i = 0; i < 18; ++i) { x[2 * i] = t[i].x; x[2 * i + 1] = t[i].y; }
-}
-// 36 doubles at stride LD (column r of the row-major staging matrix): two batches of 18 ds_read_b64
-__device__ __forceinline__ void lds_read_col36(unsigned addr, double (&x)[kNDX]) {
-    asm volatile("ds_read_b64 %0, %18 offset:0\n\tds_read_b64 %1, %18 offset:296\n\tds_read_b64 %2, %18 offset:592\n\tds_read_b64 %3, %18 offset:888\n\tds_read_b64 %4, %18 offset:1184\n\tds_read_b64 %5, %18 offset:1480\n\tds_read_b64 %6, %18 offset:1776\n\tds_read_b64 %7, %18 offset:2072\n\tds_read_b64 %8, %18 offset:2368\n\tds_read_b64 %9, %18 offset:2664\n\tds_read_b64 %10, %18 offset:2960\n\tds_read_b64 %11, %18 offset:3256\n\tds_read_b64 %12, %18 offset:3552\n\tds_read_b64 %13, %18 offset:3848\n\tds_read_b64 %14, %18 offset:4144\n\tds_read_b64 %15, %18 offset:4440\n\tds_read_b64 %16, %18 offset:4736\n\tds_read_b64 %17, %18 offset:5032\n\t" "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]), "=&v"(x[8]), "=&v"(x[9]), "=&v"(x[10]), "=&v"(x[11]), "=&v"(x[12]), "=&v"(x[13]), "=&v"(x[14]), "=&v"(x[15]), "=&v"(x[16]), "=&v"(x[17])
-                 : "v"(addr) : "memory");
-    asm volatile("ds_read_b64 %0, %18 offset:5328\n\tds_read_b64 %1, %18 offset:5624\n\tds_read_b64 %2, %18 offset:5920\n\tds_read_b64 %3, %18 offset:6216\n\tds_read_b64 %4, %18 offset:6512\n\tds_read_b64 %5, %18 offset:6808\n\tds_read_b64 %6, %18 offset:7104\n\tds_read_b64 %7, %18 offset:7400\n\tds_read_b64 %8, %18 offset:7696\n\tds_read_b64 %9, %18 offset:7992\n\tds_read_b64 %10, %18 offset:8288\n\tds_read_b64 %11, %18 offset:8584\n\tds_read_b64 %12, %18 offset:8880\n\tds_read_b64 %13, %18 offset:9176\n\tds_read_b64 %14, %18 offset:9472\n\tds_read_b64 %15, %18 offset:9768\n\tds_read_b64 %16, %18 offset:10064\n\tds_read_b64 %17, %18 offset:10360\n\t" "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(x[18]), "=&v"(x[19]), "=&v"(x[20]), "=&v"(x[21]), "=&v"(x[22]), "=&v"(x[23]), "=&v"(x[24]), "=&v"(x[25]), "=&v"(x[26]), "=&v"(x[27]), "=&v"(x[28]), "=&v"(x[29]), "=&v"(x[30]), "=&v"(x[31]), "=&v"(x[32]), "=&v"(x[33]), "=&v"(x[34]), "=&v"(x[35])
-                 : "v"(addr) : "memory");
 }
 
 struct alignas(16) BackwardLds {
@@ -374,12 +468,6 @@ __global__ __launch_bounds__(64, 2) void ik_backward_kernel(const IkBatchArgs a)
     double d1, d2, st;
 #ifdef BWD_PROFILE
     long long pc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pt0;
-#define PSTAMP(k) { const long long now_ = __builtin_readcyclecounter(); pc[k] += now_ - pt0; pt0 = now_; }
-// stamp that cannot be passed by the computation of x (nor x's consumers hoisted above it)
-#define PSTAMPV(k, x) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(x) :: "memory"); PSTAMP(k) asm volatile("" : "+v"(x) :: "memory"); }
-#else
-#define PSTAMP(k)
-#define PSTAMPV(k, x)
 #endif
     for (;;) {   // computeDirection with regularisation retries (solver-ddp.cpp solve())
         bool bad = false;
@@ -482,8 +570,9 @@ __global__ __launch_bounds__(64, 2) void ik_backward_kernel(const IkBatchArgs a)
             {
                 const unsigned kaddr = lds_offset(Ks);
                 for (int j0 = 0; j0 < kNDX; j0 += 2) {      // two columns per trip, their 18 K^T reads in flight together
-                    double2_t k0[9], k1[9];
-                    lds_read_2x18(kaddr + (unsigned)j0 * (kNV * 8), k0, k1);
+                    double2_t kk[18];
+                    lds_read_b128x18(kaddr + (unsigned)j0 * (kNV * 8), kk);
+                    const double2_t *k0 = kk, *k1 = kk + 9;
                     double w0 = s.N[r * LD + j0], w1 = s.N[r * LD + j0 + 1];
                     UNROLL_RBD for (int p = 0; p < 9; ++p) {
                         w0 -= qxu[2 * p] * k0[p].x; w1 -= qxu[2 * p] * k1[p].x;
@@ -499,7 +588,7 @@ __global__ __launch_bounds__(64, 2) void ik_backward_kernel(const IkBatchArgs a)
             lds_read_row36(row_addr, m);
             {
                 double col[kNDX];
-                lds_read_col36(col_addr, col);
+                lds_read_col36_ld37(col_addr, col);
                 UNROLL_RBD for (int j = 0; j < kNDX; ++j) {
                     m[j] = 0.5 * (m[j] + col[j]);
                     bad = bad || !(fabs(m[j]) < INFINITY);
@@ -732,7 +821,7 @@ hipError_t ik_launch_init(const IkBatchArgs &a, hipStream_t st) {
 }
 hipError_t ik_launch_calcdiff(const IkBatchArgs &a, hipStream_t st) {
     const long n = (long)a.B * (a.T + 1);
-    hipLaunchKernelGGL(ik_calcdiff_kernel, dim3((unsigned)n), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(ik_calcdiff_kernel, dim3((unsigned)n), dim3(128), 0, st, a);
     return hipGetLastError();
 }
 hipError_t ik_launch_backward(const IkBatchArgs &a, hipStream_t st) {

@@ -255,6 +255,99 @@ RBD_D void quad_column(const RobotModelDev &m, const double *x, const Pass1 &p1,
     UNROLL_RBD for (int c = 0; c < 3; ++c) { o.dh[c] = dO[c]; o.dh[3 + c] = dO[3 + c] - a3[c] - b3[c]; }
 }
 
+// ---- one chain walk per lane (calcDiff): lanes 0..5 own the base columns, lane 6 + 3 L + jsel joint jsel of leg L.
+// A lane walks only its own part of the robot and leaves (a) that part's composite / momentum about the origin
+// (to be added over the five parts: base, legs), (b) what its own column needs: motion subspace S, the composite and
+// momentum of the subtree the column moves, the parent twist.  quad_col_finish turns (b) + the totals into the column.
+struct PartWalk {
+    Comp part; double hpart[6];            // this lane's part of the robot (base body or whole leg)
+    Comp cs; double hs[6], S[6], Vpar[6];  // column data; for base columns cs / hs are the robot totals (set by the caller)
+    double fx[kFrameSlots][3];             // positions of the task frames carried by this part
+    int fhit[kFrameSlots];                 // ... and which of them are
+};
+
+RBD_D void quad_part_walk(const RobotModelDev &m, const double *x, const int *fid, int col, double *Rb, double *pb, double *Vb, PartWalk &o) {
+    quat_to_R(x + 3, Rb);
+    pb[0] = x[0]; pb[1] = x[1]; pb[2] = x[2];
+    const double *v = x + kNQ;
+    {
+        double wl[3], vl[3], t[3];
+        mat3vec(Rb, v + 3, wl); mat3vec(Rb, v, vl); cross3(pb, wl, t);
+        UNROLL_RBD for (int c = 0; c < 3; ++c) { Vb[c] = vl[c] + t[c]; Vb[3 + c] = wl[c]; }
+    }
+    int fbody[kFrameSlots];
+    UNROLL_RBD for (int s = 0; s < kFrameSlots; ++s) {
+        fbody[s] = fid[s] >= 0 ? m.frame_body[fid[s]] : -1;
+        o.fx[s][0] = o.fx[s][1] = o.fx[s][2] = 0.0;
+        o.fhit[s] = 0;
+    }
+    auto frames_on = [&](int b, const double *R, const double *p) {
+        UNROLL_RBD for (int s = 0; s < kFrameSlots; ++s)
+            if (fbody[s] == b) {
+                double t[3];
+                mat3vec(R, m.frame_p[fid[s]], t);
+                UNROLL_RBD for (int c = 0; c < 3; ++c) o.fx[s][c] = t[c] + p[c];
+                o.fhit[s] = 1;
+            }
+    };
+    BodyAcc ba;
+    if (col < 6) {
+        body_terms<true>(m, 0, Rb, pb, Vb, ba);
+        o.part = ba.c;
+        UNROLL_RBD for (int c = 0; c < 6; ++c) { o.hpart[c] = ba.h[c]; o.Vpar[c] = 0.0; }
+        frames_on(0, Rb, pb);
+        const int a = col % 3;
+        const double e[3] = {Rb[a], Rb[3 + a], Rb[6 + a]};
+        if (col < 3) { UNROLL_RBD for (int c = 0; c < 3; ++c) { o.S[c] = e[c]; o.S[3 + c] = 0.0; } }
+        else { cross3(pb, e, o.S); UNROLL_RBD for (int c = 0; c < 3; ++c) o.S[3 + c] = e[c]; }
+        return;
+    }
+    const int L = (col - 6) / kLegJoints, jsel = (col - 6) % kLegJoints;
+    double Rp[9], pp[3], Vp[6];
+    UNROLL_RBD for (int c = 0; c < 9; ++c) Rp[c] = Rb[c];
+    UNROLL_RBD for (int c = 0; c < 3; ++c) pp[c] = pb[c];
+    UNROLL_RBD for (int c = 0; c < 6; ++c) Vp[c] = Vb[c];
+    comp_zero(o.part); comp_zero(o.cs);
+    UNROLL_RBD for (int c = 0; c < 6; ++c) { o.hpart[c] = 0.0; o.hs[c] = 0.0; o.Vpar[c] = 0.0; o.S[c] = 0.0; }
+    UNROLL_RBD for (int j = 0; j < kLegJoints; ++j) {
+        const int i = kLegJoints * L + j;
+        double R[9], p[3], S[6], V[6];
+        joint_step(m, i, x[7 + i], v[6 + i], Rp, pp, Vp, R, p, S, V);
+        body_terms<true>(m, i + 1, R, p, V, ba);
+        comp_add(o.part, ba.c);
+        UNROLL_RBD for (int c = 0; c < 6; ++c) o.hpart[c] += ba.h[c];
+        if (j == jsel) { UNROLL_RBD for (int c = 0; c < 6; ++c) { o.S[c] = S[c]; o.Vpar[c] = Vp[c]; } }
+        if (j >= jsel) { comp_add(o.cs, ba.c); UNROLL_RBD for (int c = 0; c < 6; ++c) o.hs[c] += ba.h[c]; }   // subtree = joints jsel..2
+        frames_on(i + 1, R, p);
+        UNROLL_RBD for (int c = 0; c < 9; ++c) Rp[c] = R[c];
+        UNROLL_RBD for (int c = 0; c < 3; ++c) pp[c] = p[c];
+        UNROLL_RBD for (int c = 0; c < 6; ++c) Vp[c] = V[c];
+    }
+}
+
+// column from the walk + robot totals (M, com, hO): CoM-Jacobian column, A_g column, dh_g/dq column
+RBD_D void quad_col_finish(const PartWalk &w, double M, const double *com, const double *hO, Column &o) {
+    double h[6], t3[3], a3[3], b3[3];
+    UNROLL_RBD for (int c = 0; c < 6; ++c) o.S[c] = w.S[c];
+    comp_apply(w.cs, o.S, h);
+    const double iM = 1.0 / M;
+    UNROLL_RBD for (int c = 0; c < 3; ++c) o.jc[c] = h[c] * iM;
+    cross3(com, h, t3);
+    UNROLL_RBD for (int c = 0; c < 3; ++c) { o.ag[c] = h[c]; o.ag[3 + c] = h[3 + c] - t3[c]; }
+    double cf[6], sxv[6], ih[6];
+    cross3(o.S + 3, w.hs, cf);
+    cross3(o.S + 3, w.hs + 3, a3); cross3(o.S, w.hs, b3);
+    UNROLL_RBD for (int c = 0; c < 3; ++c) cf[3 + c] = a3[c] + b3[c];
+    cross3(o.S + 3, w.Vpar, a3); cross3(o.S, w.Vpar + 3, b3);
+    UNROLL_RBD for (int c = 0; c < 3; ++c) sxv[c] = a3[c] + b3[c];
+    cross3(o.S + 3, w.Vpar + 3, sxv + 3);
+    comp_apply(w.cs, sxv, ih);
+    double dO[6];
+    UNROLL_RBD for (int c = 0; c < 6; ++c) dO[c] = cf[c] - ih[c];
+    cross3(o.jc, hO, a3); cross3(com, dO, b3);
+    UNROLL_RBD for (int c = 0; c < 3; ++c) { o.dh[c] = dO[c]; o.dh[3 + c] = dO[3 + c] - a3[c] - b3[c]; }
+}
+
 // does column col move the body that carries frame f?  (legs numbered 3L..3L+2, body = joint + 1)
 RBD_D bool quad_supports(const RobotModelDev &m, int f, int col) {
     if (col < 6) return true;
