@@ -36,6 +36,26 @@ RBD_D void skew3(const double *v, double *K) {
     K[0] = 0; K[1] = -v[2]; K[2] = v[1]; K[3] = v[2]; K[4] = 0; K[5] = -v[0]; K[6] = -v[1]; K[7] = v[0]; K[8] = 0;
 }
 
+// sin and cos together, ~1 ulp, for the moderate arguments this code meets (joint angles, rotation angles <= pi;
+// fine up to |x| ~ 1e5): Cody-Waite reduction by pi/2 in two pieces + the fdlibm kernel polynomials.  The library
+// sin / cos carry a Payne-Hanek path for huge arguments and do not share their range reduction.
+RBD_D void sincos_fast(double x, double &s, double &c) {
+    const double k = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-k, 1.57079632673412561417e+00, x);
+    r = fma(-k, 6.07710050650619224932e-11, r);
+    const double z = r * r;
+    const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                      z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+    const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    const double sr = fma(r * z, ps, r);
+    const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int n = (int)k & 3;
+    const double ss = (n & 1) ? cr : sr, cc = (n & 1) ? sr : cr;
+    s = (n & 2) ? -ss : ss;
+    c = ((n + 1) & 2) ? -cc : cc;
+}
+
 // coefficients a = sin t / t, b = (1 - cos t)/t^2, c = (t - sin t)/t^3
 RBD_D void abc(double t2, double &a, double &b, double &c) {
     if (t2 < 1e-6) {
@@ -43,7 +63,9 @@ RBD_D void abc(double t2, double &a, double &b, double &c) {
         b = 0.5 - t2 / 24.0 + t2 * t2 / 720.0;
         c = 1.0 / 6.0 - t2 / 120.0 + t2 * t2 / 5040.0;
     } else {
-        const double t = sqrt(t2), st = sin(t), ct = cos(t);
+        const double t = sqrt(t2);
+        double st, ct;
+        sincos_fast(t, st, ct);
         a = st / t; b = (1.0 - ct) / t2; c = (t - st) / (t2 * t);
     }
 }
@@ -78,13 +100,15 @@ RBD_D void log3(const double *R, double *w) {
         double sg = (ax[0] * v[0] + ax[1] * v[1] + ax[2] * v[2]) < 0 ? -1.0 : 1.0;
         for (int i = 0; i < 3; ++i) w[i] = sg * t * ax[i] * s;
         return;
-    } else f = t / (2.0 * sin(t));
+    } else { double st, ct; sincos_fast(t, st, ct); f = t / (2.0 * st); }
     w[0] = f * v[0]; w[1] = f * v[1]; w[2] = f * v[2];
 }
 RBD_D double beta_of(double t2) {
     if (t2 < 1e-6) return 1.0 / 12.0 + t2 / 720.0 + t2 * t2 / 30240.0;
     const double t = sqrt(t2);
-    return 1.0 / t2 - sin(t) / (2.0 * t * (1.0 - cos(t)));
+    double st, ct;
+    sincos_fast(t, st, ct);
+    return 1.0 / t2 - st / (2.0 * t * (1.0 - ct));
 }
 RBD_D void log6(const double *R, const double *p, double *nu) {
     double K[9], K2[9];
@@ -100,7 +124,7 @@ RBD_D void jlog3(const double *w, double *J) {
     const double t2 = dot3(w, w);
     double alpha, diag;
     if (t2 < 1e-6) { alpha = 1.0 / 12.0 + t2 / 720.0 + t2 * t2 / 30240.0; diag = 0.5 * (2.0 - t2 / 6.0 - t2 * t2 / 360.0); }
-    else { const double t = sqrt(t2), s1c = sin(t) / (1.0 - cos(t)); alpha = 1.0 / t2 - s1c / (2.0 * t); diag = 0.5 * t * s1c; }
+    else { const double t = sqrt(t2); double st, ct; sincos_fast(t, st, ct); const double s1c = st / (1.0 - ct); alpha = 1.0 / t2 - s1c / (2.0 * t); diag = 0.5 * t * s1c; }
     double K[9]; skew3(w, K);
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) J[3 * i + j] = alpha * w[i] * w[j] + 0.5 * K[3 * i + j];
     J[0] += diag; J[4] += diag; J[8] += diag;
@@ -121,7 +145,9 @@ RBD_D void q_left(const double *rho, const double *phi, double *Q) {
         c2 = 1.0 / 24.0 - t2 / 720.0 + t2 * t2 / 40320.0;
         c3 = 1.0 / 120.0 - t2 / 2520.0 + t2 * t2 / 120960.0;
     } else {
-        const double t = sqrt(t2), st = sin(t), ct = cos(t);
+        const double t = sqrt(t2);
+        double st, ct;
+        sincos_fast(t, st, ct);
         c1 = (t - st) / (t2 * t);
         c2 = (t2 + 2.0 * ct - 2.0) / (2.0 * t2 * t2);
         c3 = (2.0 * t - 3.0 * st + t * ct) / (2.0 * t2 * t2 * t);
@@ -144,9 +170,8 @@ RBD_D void jexp6(const double *nu, double *J) {
     }
 }
 // d log6(M exp6(d))/dd at 0 = [[A, -A Q A],[0, A]], A = jlog3(w), Q = q_left(-nu)
-RBD_D void jlog6(const double *R, const double *p, double *J) {
-    double nu[6], A[9], Q[9], AQ[9], AQA[9];
-    log6(R, p, nu);
+RBD_D void jlog6_of(const double *nu, double *J) {   // nu = log6(M), already at hand
+    double A[9], Q[9], AQ[9], AQA[9];
     const double mn[6] = {-nu[0], -nu[1], -nu[2], -nu[3], -nu[4], -nu[5]};
     jlog3(nu + 3, A); q_left(mn, mn + 3, Q);
     mat3mul(A, Q, AQ); mat3mul(AQ, A, AQA);
@@ -181,7 +206,7 @@ RBD_D void state_integrate(const double *x, const double *dx, double *xn) {
     // quaternion of exp3(w): (sin(t/2)/t w, cos(t/2))
     const double t2 = dot3(dx + 3, dx + 3), th = sqrt(t2);
     double s, cw;
-    if (t2 < 1e-8) { s = 0.5 - t2 / 48.0; cw = 1.0 - t2 / 8.0; } else { s = sin(0.5 * th) / th; cw = cos(0.5 * th); }
+    if (t2 < 1e-8) { s = 0.5 - t2 / 48.0; cw = 1.0 - t2 / 8.0; } else { double sh; sincos_fast(0.5 * th, sh, cw); s = sh / th; }
     const double d[4] = {s * dx[3], s * dx[4], s * dx[5], cw};
     const double nq = 1.0 / sqrt(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] + x[6] * x[6]);
     const double q[4] = {x[3] * nq, x[4] * nq, x[5] * nq, x[6] * nq};
@@ -206,7 +231,7 @@ RBD_D void state_diff(const double *x0, const double *x1, double *d, double *Jl)
     log6(Rr, pr, d);
     _Pragma("unroll") for (int i = 0; i < kNV - 6; ++i) d[6 + i] = x1[7 + i] - x0[7 + i];
     _Pragma("unroll") for (int i = 0; i < kNV; ++i) d[kNV + i] = x1[kNQ + i] - x0[kNQ + i];
-    if (JAC) jlog6(Rr, pr, Jl);
+    if (JAC) jlog6_of(d, Jl);
 }
 
 // composite inertia about the world origin: mass, first moment h1 = m c, I_O (xx xy xz yy yz zz)

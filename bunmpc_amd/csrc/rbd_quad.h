@@ -19,7 +19,9 @@ constexpr int kLegs = 4, kLegJoints = 3;
 struct BodyAcc { Comp c; double h[6]; };   // composite about the world origin + momentum
 
 RBD_D void rodrigues(const double *a, double q, double *R) {   // unit axis: R = c I + s [a]x + (1 - c) a a^T
-    const double s = sin(q), c = cos(q), c1 = 1.0 - c;
+    double s, c;
+    sincos_fast(q, s, c);
+    const double c1 = 1.0 - c;
     R[0] = c + c1 * a[0] * a[0]; R[1] = c1 * a[0] * a[1] - s * a[2]; R[2] = c1 * a[0] * a[2] + s * a[1];
     R[3] = c1 * a[1] * a[0] + s * a[2]; R[4] = c + c1 * a[1] * a[1]; R[5] = c1 * a[1] * a[2] - s * a[0];
     R[6] = c1 * a[2] * a[0] - s * a[1]; R[7] = c1 * a[2] * a[1] + s * a[0]; R[8] = c + c1 * a[2] * a[2];
