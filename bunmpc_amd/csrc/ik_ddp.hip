@@ -622,16 +622,27 @@ __global__ __launch_bounds__(64, 2) void ik_backward_kernel(const IkBatchArgs a)
 }
 
 // ---------------------------------------------------------------------------- forward ---
-struct ForwardLds { RobotModelDev m; double dx[kNDX], u[kNV], x[kNX], xn[kNX]; double part[kLegs + 1][10 + 3 * kFrameSlots]; double bc[4]; };
+// Line search + rollout.  FOUR problems per wave, 16 lanes each: the rollout of one problem is a serial chain whose
+// pieces run on a handful of lanes (one lane for the SE(3) difference, 16 for the feedback rows, five for the legs
+// and the base, one for the state cost, one for the control cost and the Euler step), and pieces with different code
+// cannot overlap inside a wave -- so a wave carries four independent chains through the same instruction stream.
+constexpr int kFwdSub = 4, kFwdLanes = 64 / kFwdSub;
+
+struct FwdSub { double dx[kNDX], u[kNV], x[kNX], xn[kNX]; double part[kLegs + 1][10 + 3 * kFrameSlots]; double bc[4]; };
+struct ForwardLds { RobotModelDev m; FwdSub sub[kFwdSub]; };
 
 __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
     __shared__ ForwardLds s;
-    const long b = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x, si = lane / kFwdLanes, l = lane % kFwdLanes;
+    const long b = (long)blockIdx.x * kFwdSub + si;
+    const bool pvalid = b < a.B;
+    const long bb = pvalid ? b : 0;
     const IkLayout L = IkLayout::make(a.T);
-    double *ws = a.ws + b * L.total;
+    double *ws = a.ws + bb * L.total;
     double *sc = ws + L.scal;
-    if (sc[S_DONE] != 0.0) return;
+    FwdSub &q = s.sub[si];
+    bool live = pvalid && sc[S_DONE] == 0.0;     // this sub-group still has a line search to do
+    if (!__any(live)) return;
     const int T = a.T, nn = a.T + 1;
     {   // the robot model is read many times per node: stage it in LDS once
         const int *src = reinterpret_cast<const int *>(a.model);
@@ -642,73 +653,78 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
     const RobotModelDev &m = s.m;
     const double cost = sc[S_COST], d1 = sc[S_D1], d2 = sc[S_D2];
     const bool feas = sc[S_FEAS] != 0.0;
-    const double *state_w = batch_ptr(a.state_w, a.s_state_w, b), *ctrl_w = batch_ptr(a.ctrl_w, a.s_ctrl_w, b);
-    const double *x_reg = a.x_reg + b * kNX;
+    const double *state_w = batch_ptr(a.state_w, a.s_state_w, bb), *ctrl_w = batch_ptr(a.ctrl_w, a.s_ctrl_w, bb);
+    const double *x_reg = a.x_reg + bb * kNX;
+    const bool owner = live;            // sub-groups that take part at all
     bool accepted = false;
     double alpha = 1.0, cost_try = 0.0;
-    for (int ia = 0; ia < 10; ++ia) {   // alphas_ = 2^-n, n = 0..9
-        alpha = ldexp(1.0, -ia);
-        bool failed = false;
-        cost_try = 0.0;
-        if (lane < kNX) s.x[lane] = ws[L.xs_try + lane];
+    for (int ia = 0; ia < 10; ++ia) {   // alphas_ = 2^-n, n = 0..9; a sub-group that has accepted waits for the others
+        if (!__any(live)) break;
+        if (live) alpha = ldexp(1.0, -ia);
+        bool run = live;                // false once this trial has failed (tryStep threw)
+        double ctry = 0.0;
+        if (run) { for (int i = l; i < kNX; i += kFwdLanes) q.x[i] = ws[L.xs_try + i]; }
         __syncthreads();
-        for (int t = 0; t <= T && !failed; ++t) {   // t == T: terminal node (cost only)
+        for (int t = 0; t <= T; ++t) {   // t == T: terminal node (cost only)
+            if (!__any(run)) break;
             const bool terminal = t == T;
             if (!terminal) {
-                if (lane == 0) state_diff<false>(ws + L.xs + (long)t * kNX, s.x, s.dx, nullptr);
+                if (run && l == 0) state_diff<false>(ws + L.xs + (long)t * kNX, q.x, q.dx, nullptr);
                 __syncthreads();
-                if (lane < kNV) {
-                    const double *Kr = ws + L.K + (long)t * kNV * kNDX + (long)lane * kNDX;
-                    double v = ws[L.us + (long)t * kNV + lane] - alpha * ws[L.kff + (long)t * kNV + lane];
-                    UNROLL_RBD for (int j = 0; j < kNDX; ++j) v -= Kr[j] * s.dx[j];
-                    s.u[lane] = v;
-                    ws[L.us_try + (long)t * kNV + lane] = v;
+                if (run) {
+                    for (int row = l; row < kNV; row += kFwdLanes) {
+                        const double *Kr = ws + L.K + (long)t * kNV * kNDX + (long)row * kNDX;
+                        double v = ws[L.us + (long)t * kNV + row] - alpha * ws[L.kff + (long)t * kNV + row];
+                        UNROLL_RBD for (int j = 0; j < kNDX; ++j) v -= Kr[j] * q.dx[j];
+                        q.u[row] = v;
+                        ws[L.us_try + (long)t * kNV + row] = v;
+                    }
                 }
                 __syncthreads();
             }
-            // node evaluation spread over lanes: 0..3 legs, 4 base body, 5 state residual, 6 control cost + Euler step
-            NodeTasks tk{a.tasks + (b * nn + t) * kNodeTaskDoubles};
-            const double dtn = terminal ? 0.0 : a.dt[b * T + t];
-            if (lane <= kLegs) {
+            // node evaluation spread over the sub-group's lanes: 0..3 legs, 4 base body, 5 state residual, 6 control cost + Euler step
+            NodeTasks tk{a.tasks + (bb * nn + t) * kNodeTaskDoubles};
+            const double dtn = terminal ? 0.0 : a.dt[bb * T + t];
+            if (run && l <= kLegs) {
                 int fid[kFrameSlots];
                 UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) fid[f] = tk.frame_w(f) != 0.0 ? tk.frame_id(f) : -1;
                 PartSum ps;
-                quad_part(m, s.x, fid, lane, ps);
-                s.part[lane][0] = ps.mass;
-                UNROLL_RBD for (int c = 0; c < 3; ++c) s.part[lane][1 + c] = ps.h1[c];
-                UNROLL_RBD for (int c = 0; c < 6; ++c) s.part[lane][4 + c] = ps.hO[c];
+                quad_part(m, q.x, fid, l, ps);
+                q.part[l][0] = ps.mass;
+                UNROLL_RBD for (int c = 0; c < 3; ++c) q.part[l][1 + c] = ps.h1[c];
+                UNROLL_RBD for (int c = 0; c < 6; ++c) q.part[l][4 + c] = ps.hO[c];
                 UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
-                    UNROLL_RBD for (int c = 0; c < 3; ++c) s.part[lane][10 + 3 * f + c] = ps.fhit[f] ? ps.fx[f][c] : 0.0;
-            } else if (lane == 5) {
+                    UNROLL_RBD for (int c = 0; c < 3; ++c) q.part[l][10 + 3 * f + c] = ps.fhit[f] ? ps.fx[f][c] : 0.0;
+            } else if (run && l == 5) {
                 double acc = 0.0;
                 if (tk.state_w() != 0.0) {
                     double rs[kNDX];
-                    state_diff<false>(x_reg, s.x, rs, nullptr);
+                    state_diff<false>(x_reg, q.x, rs, nullptr);
                     UNROLL_RBD for (int i = 0; i < kNDX; ++i) acc += state_w[i] * rs[i] * rs[i];
                 }
-                s.bc[2] = tk.state_w() * 0.5 * acc;
-            } else if (lane == 6) {
+                q.bc[2] = tk.state_w() * 0.5 * acc;
+            } else if (run && l == 6) {
                 double acc = 0.0;
                 if (!terminal) {
-                    UNROLL_RBD for (int i = 0; i < kNV; ++i) acc += ctrl_w[i] * s.u[i] * s.u[i];
+                    UNROLL_RBD for (int i = 0; i < kNV; ++i) acc += ctrl_w[i] * q.u[i] * q.u[i];
                     double xn[kNX];
-                    euler_step<false>(s.x, s.u, dtn, xn, nullptr, nullptr);
+                    euler_step<false>(q.x, q.u, dtn, xn, nullptr, nullptr);
                     bool bad = false;
-                    UNROLL_RBD for (int i = 0; i < kNX; ++i) { ws[L.xs_try + (long)(t + 1) * kNX + i] = xn[i]; s.xn[i] = xn[i]; bad = bad || !(fabs(xn[i]) < INFINITY); }
-                    s.bc[1] = bad ? 1.0 : 0.0;
-                } else s.bc[1] = 0.0;
-                s.bc[3] = tk.ctrl_w() * 0.5 * acc;
+                    UNROLL_RBD for (int i = 0; i < kNX; ++i) { ws[L.xs_try + (long)(t + 1) * kNX + i] = xn[i]; q.xn[i] = xn[i]; bad = bad || !(fabs(xn[i]) < INFINITY); }
+                    q.bc[1] = bad ? 1.0 : 0.0;
+                } else q.bc[1] = 0.0;
+                q.bc[3] = tk.ctrl_w() * 0.5 * acc;
             }
             __syncthreads();
-            if (lane == 0) {   // add the parts: CoM, centroidal momentum, residual costs
+            if (run && l == 0) {   // add the parts: CoM, centroidal momentum, residual costs
                 double M = 0.0, h1[3] = {0, 0, 0}, hO[6] = {0, 0, 0, 0, 0, 0}, fx[kFrameSlots][3];
                 UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) fx[f][0] = fx[f][1] = fx[f][2] = 0.0;
                 UNROLL_RBD for (int pa = 0; pa <= kLegs; ++pa) {
-                    M += s.part[pa][0];
-                    UNROLL_RBD for (int c = 0; c < 3; ++c) h1[c] += s.part[pa][1 + c];
-                    UNROLL_RBD for (int c = 0; c < 6; ++c) hO[c] += s.part[pa][4 + c];
+                    M += q.part[pa][0];
+                    UNROLL_RBD for (int c = 0; c < 3; ++c) h1[c] += q.part[pa][1 + c];
+                    UNROLL_RBD for (int c = 0; c < 6; ++c) hO[c] += q.part[pa][4 + c];
                     UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
-                        UNROLL_RBD for (int c = 0; c < 3; ++c) fx[f][c] += s.part[pa][10 + 3 * f + c];
+                        UNROLL_RBD for (int c = 0; c < 3; ++c) fx[f][c] += q.part[pa][10 + 3 * f + c];
                 }
                 double com[3], t3[3], c = 0.0, acc = 0.0;
                 UNROLL_RBD for (int k = 0; k < 3; ++k) com[k] = h1[k] / M;
@@ -727,26 +743,31 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
                     UNROLL_RBD for (int k = 0; k < 3; ++k) { const double r = w != 0.0 ? fx[f][k] - tk.frame_ref(f)[k] : 0.0; acc += r * r; }
                     c += w * 0.5 * acc;
                 }
-                c += s.bc[2] + s.bc[3];
+                c += q.bc[2] + q.bc[3];
                 if (!terminal) c *= dtn;
-                if (!(fabs(c) < INFINITY)) s.bc[1] = 1.0;
-                s.bc[0] = c;
+                if (!(fabs(c) < INFINITY)) q.bc[1] = 1.0;
+                q.bc[0] = c;
             }
             __syncthreads();
-            if (lane < kNX && !terminal) s.x[lane] = s.xn[lane];
-            cost_try += s.bc[0];
-            failed = s.bc[1] != 0.0;
+            if (run) {
+                if (!terminal) { for (int i = l; i < kNX; i += kFwdLanes) q.x[i] = q.xn[i]; }
+                ctry += q.bc[0];
+                if (q.bc[1] != 0.0) run = false;       // tryStep threw: this sub-group goes on to the next step length
+            }
             __syncthreads();
         }
-        if (failed) continue;   // tryStep threw: next step length
-        const double dV = cost - cost_try;
-        const double dVexp = alpha * (d1 + 0.5 * alpha * d2);
-        if (dVexp >= 0.0 && (d1 < 1e-12 || !feas || dV > 0.1 * dVexp)) { accepted = true; break; }
+        if (live && run) {       // the trial ran to the end
+            cost_try = ctry;
+            const double dV = cost - cost_try;
+            const double dVexp = alpha * (d1 + 0.5 * alpha * d2);
+            if (dVexp >= 0.0 && (d1 < 1e-12 || !feas || dV > 0.1 * dVexp)) { accepted = true; live = false; }
+        }
     }
+    if (!owner) return;
     double xreg = sc[S_XREG];
     if (accepted) {   // setCandidate(xs_try, us_try, true)
-        for (long i = lane; i < (long)nn * kNX; i += 64) ws[L.xs + i] = ws[L.xs_try + i];
-        for (long i = lane; i < (long)T * kNV; i += 64) ws[L.us + i] = ws[L.us_try + i];
+        for (long i = l; i < (long)nn * kNX; i += kFwdLanes) ws[L.xs + i] = ws[L.xs_try + i];
+        for (long i = l; i < (long)T * kNV; i += kFwdLanes) ws[L.us + i] = ws[L.us_try + i];
     }
     if (alpha > 0.5) xreg = fmax(xreg / 10.0, 1e-9);          // decreaseRegularization
     bool done = false;
@@ -759,8 +780,8 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
     const double iters = sc[S_ITERS] + 1.0;
     if (!done && wasfeas_new && sc[S_STOP] < 1e-9) { done = true; status = 0.0; }       // converged
     if (!done && iters >= (double)a.maxiter) { done = true; status = 1.0; }             // maxiter reached
-    __syncthreads();
-    if (lane == 0) {
+    __builtin_amdgcn_wave_barrier();
+    if (l == 0) {
         if (accepted) { sc[S_WASFEAS] = feas ? 1.0 : 0.0; sc[S_FEAS] = 1.0; sc[S_COST] = cost_try; sc[S_RECALC] = 1.0; }
         else sc[S_RECALC] = 0.0;
         sc[S_XREG] = xreg; sc[S_ITERS] = iters;
@@ -829,7 +850,7 @@ hipError_t ik_launch_backward(const IkBatchArgs &a, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t ik_launch_forward(const IkBatchArgs &a, hipStream_t st) {
-    hipLaunchKernelGGL(ik_forward_kernel, dim3(a.B), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(ik_forward_kernel, dim3((a.B + 3) / 4), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 hipError_t ik_launch_centroidal_state(const RobotModelDev *model, const double *x, double *out9, int B, hipStream_t st) {
