@@ -30,6 +30,20 @@ class Batch(C.Structure):
                                            "L_x", "L_f", "dyn_viol", "hist", "stats")])
 
 
+class GaitParams(C.Structure):
+    """bmpc_gait_params_t"""
+    _fields_ = [("gait_period", C.c_double), ("gait_dt", C.c_double), ("gait_horizon", C.c_double), ("nom_ht", C.c_double),
+                ("stance_percent", C.c_double * 4), ("phase_offset", C.c_double * 4), ("ori_correction", C.c_double * 3),
+                ("offsets_xy", (C.c_double * 2) * 4)]
+
+
+class PlanBatch(C.Structure):
+    """bmpc_plan_batch_t"""
+    _fields_ = ([("B", C.c_int), ("n_col", C.c_int), ("n_gaits", C.c_int), ("reserved_", C.c_int)] +
+                [(n, C.c_void_p) for n in ("gaits", "gait_id", "t0", "com", "feet0", "v_des", "w_des", "x_init", "amom",
+                                           "hip_off", "cnt_plan", "swing_time", "dt", "X_nom", "X_ter")])
+
+
 _lib = None
 
 _D = C.c_double
@@ -92,6 +106,7 @@ _SIGS = {
     "bmpc_biconvex_solve_batch_device": (_I, [_P, _P]),
     "bmpc_biconvex_solve_batch_host": (_I, [_P]),
     "bmpc_biconvex_kernel_name": (C.c_char_p, [_I, _I]),
+    "bmpc_plan_batch_device": (_I, [_P, _P]),
     "bmpc_model_create": (_P, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "bmpc_model_destroy": (None, [_P]),
     "bmpc_model_total_mass": (_D, [_P]),

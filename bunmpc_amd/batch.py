@@ -40,7 +40,9 @@ class DeviceBatch:
     create_cost_F / create_bound_constraints itself)."""
 
     def __init__(self, batch, device="cuda", num_iters=10, maxit=150, tol=1e-5, exit_tol=1e-3,
-                 beta=1.5, mu=None, keep_hist=False, precision="f64"):
+                 beta=1.5, mu=None, keep_hist=False, precision="f64", plan=None):
+        """plan: a plan_batch.DevicePlan whose tensors (cnt_plan, dt, X_nom, X_ter, x_init) are used in place of the
+        batch's host arrays -- inputs built on the GPU never leave HBM"""
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("DeviceBatch needs a GPU: no CPU fallback exists for the solve")
@@ -54,9 +56,13 @@ class DeviceBatch:
         def up(a):
             return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
 
-        self.t = dict(cnt_plan=up(batch.cnt_plan), dt=up(batch.dt), x_init=up(batch.x_init),
-                      W_X=up(batch.W_X), W_X_ter=up(batch.W_X_ter), W_F=up(batch.W_F),
-                      bounds=up(batch.bounds), X_nom=up(batch.X_nom), X_ter=up(batch.X_ter))
+        if plan is None:
+            self.t = dict(cnt_plan=up(batch.cnt_plan), dt=up(batch.dt), x_init=up(batch.x_init),
+                          X_nom=up(batch.X_nom), X_ter=up(batch.X_ter))
+        else:
+            assert plan.B == B and plan.H == H
+            self.t = dict(cnt_plan=plan.cnt_plan, dt=plan.dt, x_init=plan.inp["x_init"], X_nom=plan.X_nom, X_ter=plan.X_ter)
+        self.t.update(W_X=up(batch.W_X), W_X_ter=up(batch.W_X_ter), W_F=up(batch.W_F), bounds=up(batch.bounds))
         self.X = torch.empty((B, 9 * (H + 1)), dtype=f64, device=self.device)
         self.F = torch.empty((B, 3 * E * H), dtype=f64, device=self.device)
         self.P = torch.empty((B, 9 * (H + 1)), dtype=f64, device=self.device)

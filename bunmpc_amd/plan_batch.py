@@ -1,0 +1,62 @@
+"""Harness inputs built on the GPU (bmpc_plan_batch_device in include/bunmpc.h): contact plan, swing flags, dt, X_nom,
+X_ter for B problems from their current CoM / feet / time / desired velocities, left in HBM for
+`bmpc_biconvex_solve_batch_device`.  Device counterpart of problems.contact_plan / centroidal_costs."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def gait_struct(gait, offsets_xy):
+    g = _lib.GaitParams()
+    g.gait_period, g.gait_dt, g.gait_horizon, g.nom_ht = gait.gait_period, gait.gait_dt, gait.gait_horizon, gait.nom_ht
+    for j in range(4):
+        g.stance_percent[j], g.phase_offset[j] = gait.stance_percent[j], gait.phase_offset[j]
+        g.offsets_xy[j][0], g.offsets_xy[j][1] = offsets_xy[j][0], offsets_xy[j][1]
+    for k in range(3):
+        g.ori_correction[k] = gait.ori_correction[k]
+    return g
+
+
+class DevicePlan:
+    """Builds (and keeps) the plan tensors of one batch on `device`.  Inputs are numpy arrays or torch tensors:
+    t0 (B,), com (B,3), feet0 (B,4,3), v_des (B,3), w_des (B,), x_init (B,9), optional amom (B,3), hip_off (B,4,2),
+    gait_id (B,) into `gaits` (list of GaitParams with the robot's hip offsets)."""
+
+    def __init__(self, gaits, offsets_xy, H, t0, com, feet0, v_des, w_des, x_init, amom=None, hip_off=None, gait_id=None,
+                 device="cuda"):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("DevicePlan needs a GPU")
+        self.torch, self.device = torch, torch.device(device)
+        f64 = torch.float64
+
+        def up(a, dtype=f64):
+            return None if a is None else torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a, dtype=dtype, device=self.device).contiguous()
+
+        B = int(np.shape(t0)[0])
+        self.B, self.H = B, H
+        raw = (_lib.GaitParams * len(gaits))(*[gait_struct(g, offsets_xy) for g in gaits])
+        self.gaits = torch.frombuffer(bytearray(bytes(raw)), dtype=torch.uint8).to(self.device)
+        self.inp = dict(t0=up(t0), com=up(com), feet0=up(feet0), v_des=up(v_des), w_des=up(w_des), x_init=up(x_init),
+                        amom=up(amom), hip_off=up(hip_off), gait_id=up(gait_id, torch.int32))
+        self.cnt_plan = torch.empty((B, H, 4, 4), dtype=f64, device=self.device)
+        self.swing_time = torch.empty((B, H, 4), dtype=f64, device=self.device)
+        self.dt = torch.empty((B, H), dtype=f64, device=self.device)
+        self.X_nom = torch.empty((B, 9 * H), dtype=f64, device=self.device)
+        self.X_ter = torch.empty((B, 9), dtype=f64, device=self.device)
+        d = _lib.PlanBatch()
+        d.B, d.n_col, d.n_gaits = B, H, len(gaits)
+        d.gaits = self.gaits.data_ptr()
+        for k, v in self.inp.items():
+            setattr(d, k, None if v is None else v.data_ptr())
+        for k in ("cnt_plan", "swing_time", "dt", "X_nom", "X_ter"):
+            setattr(d, k, getattr(self, k).data_ptr())
+        self.desc = d
+
+    def build(self):
+        """asynchronous on torch's current stream"""
+        stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().bmpc_plan_batch_device(C.byref(self.desc), C.c_void_p(stream)))
+        return self

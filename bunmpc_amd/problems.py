@@ -288,6 +288,7 @@ def make_batch(config, B, first=0, seed=None, H=None):
         x_init[:, 3:6] += nrm[:, 3:6] * 0.1
         x_init[:, 6:9] += nrm[:, 6:9] * 0.02
         feet0[:, :, 0:2] += 0.01 * nrm[:, 9:17].reshape(B, E, 2)
+    feet0_raw = feet0.copy()
     feet0 = np.round(feet0, 3)                       # :215 np.round(oMf.translation, 3)
     com_xy = np.round(x_init[:, 0:2], 3)             # :164
     w_des = np.zeros(B)
@@ -316,7 +317,8 @@ def make_batch(config, B, first=0, seed=None, H=None):
     bounds = np.tile(BOUNDS_TILE, (H, 1))[None]
     return Batch(config, B, H, E, robot.mass, gaits[0].rho, cnt, dt, x_init, X_nom, X_ter,
                  W_X, W_X_ter, W_F, bounds, swing, gid, 10.0 if config == "go2_bound" else 1.0,
-                 dict(seed=seed, first=first, t0=t0, v_des=v_des, gaits=[g.name for g in gaits]))
+                 dict(seed=seed, first=first, t0=t0, v_des=v_des, gaits=[g.name for g in gaits], gait_objs=gaits, robot=robot,
+                      feet0_raw=feet0_raw, w_des=w_des))
 
 
 # ------------------------------------------------------------------- whole-body batches ---

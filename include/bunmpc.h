@@ -239,6 +239,34 @@ typedef struct {
 } bmpc_kinodyn_batch_t;
 int bmpc_kinodyn_solve_batch_device(const bmpc_kinodyn_batch_t *d, void *hip_stream);
 
+/* harness inputs on the device (additive; SURVEY 8f-1, centroidal level) -----------------------------
+ * What SoloMpcGaitGen.create_cnt_plan / create_costs compute per MPC call (abstract_cyclic_gen.py:159-414, 564-607)
+ * for B problems at once, data path only (no MCTS locations, noise or height map): from the current CoM, foot
+ * positions, time, desired velocities -> cnt_plan [B][H][4][4], swing_time [B][H][4], dt [B][H], X_nom [B][9H],
+ * X_ter [B][9], ready to be handed to bmpc_biconvex_solve_batch_device without leaving HBM.  The gait table is
+ * DEVICE memory as well (n_gaits entries; gait_id [B] selects, NULL = entry 0). */
+typedef struct {
+    double gait_period, gait_dt, gait_horizon, nom_ht;
+    double stance_percent[4], phase_offset[4];
+    double ori_correction[3];
+    double offsets_xy[4][2];     /* hip offsets from the CoM after the harness' rounding and +-0.04 widening (:56-72) */
+} bmpc_gait_params_t;
+typedef struct {
+    int B, n_col, n_gaits, reserved_;
+    const bmpc_gait_params_t *gaits;   /* device */
+    const int *gait_id;                /* [B] or NULL */
+    const double *t0;                  /* [B] */
+    const double *com;                 /* [B][3] centre of mass (xy are rounded to 3 decimals inside, :164) */
+    const double *feet0;               /* [B][4][3] current foot positions (rounded inside, :215) */
+    const double *v_des;               /* [B][3] desired CoM velocity, already in the yaw frame */
+    const double *w_des;               /* [B] */
+    const double *x_init;              /* [B][9] centroidal state */
+    const double *amom;                /* [B][3] orientation-correction momentum (:616-627) or NULL */
+    const double *hip_off;             /* [B][4][2] yaw-rotated hip offsets or NULL (gaits[].offsets_xy) */
+    double *cnt_plan, *swing_time, *dt, *X_nom, *X_ter;
+} bmpc_plan_batch_t;
+int bmpc_plan_batch_device(const bmpc_plan_batch_t *d, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,62 @@
+"""Device-side harness inputs (bmpc_plan_batch_device, csrc/plan_gen.hip) against the numpy builders of
+bunmpc_amd/problems.py (themselves a restatement of abstract_cyclic_gen.py:159-414, 564-607): bit for bit."""
+import numpy as np
+import pytest
+
+from bunmpc_amd import problems
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def device_plan(b):
+    from bunmpc_amd.plan_batch import DevicePlan
+    m = b.meta
+    com = b.x_init[:, 0:3].copy()
+    return DevicePlan(m["gait_objs"], m["robot"].offsets_xy, b.H, m["t0"], com, m["feet0_raw"], m["v_des"], m["w_des"], b.x_init,
+                      gait_id=b.gait_id.astype(np.int32) if len(m["gait_objs"]) > 1 else None).build()
+
+
+@pytest.mark.parametrize("config,B,H", [("solo12_trot", 96, None), ("solo12_mixed", 96, None), ("go2_bound", 33, 40), ("solo12_trot", 5, 63)])
+def test_plan_is_bit_identical_to_the_numpy_builders(config, B, H):
+    b = problems.make_batch(config, B, H=H) if H else problems.make_batch(config, B)
+    p = device_plan(b)
+    assert np.array_equal(p.cnt_plan.cpu().numpy(), b.cnt_plan)
+    assert np.array_equal(p.swing_time.cpu().numpy(), b.swing_time)
+    assert np.array_equal(p.dt.cpu().numpy(), b.dt)
+    assert np.array_equal(p.X_nom.cpu().numpy(), b.X_nom)
+    assert np.array_equal(p.X_ter.cpu().numpy(), b.X_ter)
+
+
+def test_turning_and_off_grid_times():
+    """w_des != 0 (centrifugal term) and t0 between knots (first-knot dt rule) through the numpy builder directly"""
+    from bunmpc_amd.plan_batch import DevicePlan
+    B, H = 40, 20
+    rng = np.random.default_rng(5)
+    t0 = np.round(rng.uniform(0, 0.5, B), 2)
+    com = np.c_[rng.normal(0, 0.02, (B, 2)), 0.22 + rng.normal(0, 0.01, B)]
+    feet0 = np.concatenate([problems.SOLO12.feet_xy[None] + rng.normal(0, 0.01, (B, 4, 2)), np.full((B, 4, 1), 0.018)], axis=2)
+    v_des = np.c_[rng.uniform(0, 0.3, B), rng.uniform(-0.1, 0.1, B), np.zeros(B)]
+    w_des = rng.uniform(-0.5, 0.5, B)
+    x_init = np.c_[com, rng.normal(0, 0.1, (B, 3)), rng.normal(0, 0.02, (B, 3))]
+    amom = rng.normal(0, 0.05, (B, 3))
+    cnt, swing, dt = problems.contact_plan(problems.TROT, problems.SOLO12, H, t0, np.round(com[:, :2], 3), com[:, 2], np.round(feet0, 3),
+                                           v_des, w_des)
+    X_nom, X_ter = problems.centroidal_costs(problems.TROT, H, x_init, v_des, dt, amom)
+    p = DevicePlan([problems.TROT], problems.SOLO12.offsets_xy, H, t0, com, feet0, v_des, w_des, x_init, amom=amom).build()
+    assert np.array_equal(p.cnt_plan.cpu().numpy(), cnt) and np.array_equal(p.swing_time.cpu().numpy(), swing)
+    assert np.array_equal(p.dt.cpu().numpy(), dt)
+    assert np.array_equal(p.X_nom.cpu().numpy(), X_nom) and np.array_equal(p.X_ter.cpu().numpy(), X_ter)
+
+
+def test_solve_from_device_built_inputs(oracle):
+    """plan built on the GPU -> batched solve, nothing through the host: same result as the host-built batch"""
+    from bunmpc_amd import batch as bb
+    b = problems.make_batch("solo12_trot", 64)
+    dev = bb.DeviceBatch(b, num_iters=10, plan=device_plan(b))
+    dev.solve()
+    got = dev.results()
+    ref = bb.solve_host(b, num_iters=10)
+    for k in "XFP":
+        assert np.array_equal(got[k], ref[k])
+    assert np.all(rel_l2(got["X"], oracle.solve_batch(b, num_iters=10)["X"]) < 1e-5)
