@@ -9,19 +9,18 @@
 //
 // MI355X organisation (nothing like crocoddyl's object graph): three kernels per DDP iteration over
 // the whole batch, all per-problem state in one contiguous HBM workspace (IkLayout):
-//   ik_calcdiff_kernel  one WAVE per (problem, node): every lane runs the register-resident robot
-//                       pass (rbd_quad.h), lanes 0..17 each own one velocity column (CoM Jacobian,
-//                       A_g, dh_g/dq, frame Jacobians) written to LDS, then all 64 lanes assemble
-//                       the Gauss-Newton L_x / L_xx from those rows (coalesced 10 KB store).
+//   ik_calcdiff_kernel  TWO waves per (problem, node): wave 0 walks the robot once (lane = velocity column, part sums
+//                       through LDS), wave 1 does the state residual / Euler step Jacobians meanwhile; both then
+//                       assemble the Gauss-Newton L_x / L_xx by column (coalesced 10 KB store).
 //   ik_backward_kernel  one WAVE per problem, matrix rows in registers (lane r = row r of V, G, Q_xx), exploiting
 //                       F_x = [[A, dt B],[0, I]], F_u = dt F_x[:, v] (A, B identity except a 6x6 free-flyer block):
 //                       G = F_x^T V F_x via one LDS transposition, Cholesky and the gain solves in registers
 //                       over v_readlane, V_xx = Q_xx - Q_xu K against broadcast LDS reads; regularisation
 //                       retries inside the kernel (details above the kernel).
-//   ik_forward_kernel   one WAVE per problem: line search 2^-k, k = 0..9 -- lanes 0..17 apply the
-//                       feedback u = u - a k - K dx, the node evaluation is spread over lanes (legs, base,
-//                       state cost, control cost + Euler step); acceptance, regularisation update and
-//                       stopping test as crocoddyl 1.9.0 solver-ddp.cpp.
+//   ik_forward_kernel   FOUR problems per wave (16 lanes each): line search 2^-k, k = 0..9 -- feedback
+//                       u = u - a k - K dx, node evaluation spread over the sub-group's lanes (legs, base, state
+//                       cost, control cost + Euler step); acceptance, regularisation update and stopping test
+//                       as crocoddyl 1.9.0 solver-ddp.cpp.
 // The host loops over DDP iterations and stops when the device-side active counter reaches zero.
 #include "ik_types.h"
 #include "rbd_quad.h"
