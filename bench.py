@@ -170,11 +170,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the solve)")
+    # rehearsal of the N > 1 path on a one-GPU box: every rank on cuda:0, gloo instead of RCCL (never used by the driver)
+    rehearsal = os.environ.get("BUNMPC_BENCH_ONE_DEVICE") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     if args.gpus != world and rank == 0:
         print("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
@@ -206,6 +213,8 @@ def main():
     counts = torch.tensor([float((res["stats"][:, 5] != 0).sum()), float(res["stats"][:, 1:3].sum()),
                            flops_from_stats(res["stats"], pb.H)], dtype=torch.float64, device=dev)
     if world > 1:
+        if rehearsal:
+            tele, counts = tele.cpu(), counts.cpu()
         dist.all_reduce(tele, op=dist.ReduceOp.MAX)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     elapsed, kern_ms = float(tele[0]), float(tele[1])
