@@ -143,12 +143,19 @@ bunmpc::IkBatchArgs make_args(int B, int T, int maxiter, const bmpc_model *model
 }
 
 // the DDP iteration loop (SolverDDP::solve): three launches per iteration, stop when every problem is done
-int run_ddp(const bunmpc::IkBatchArgs &a, hipStream_t st, int *iters_run) {
+// below this many active problems the forward pass runs four step lengths of a problem side by side (one wave per
+// problem: 1024 SIMDs on an MI355X)
+constexpr int kSpecLineSearchBelow = 1024;
+
+int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run) {
+    bunmpc::IkBatchArgs a = a0;
+    a.fwd_spec = 0;
     HIP_TRY(bunmpc::ik_launch_init(a, st));
     int active = a.B, it = 0;
     for (; it < a.maxiter && active > 0; ++it) {
         HIP_TRY(bunmpc::ik_launch_calcdiff(a, st));
         HIP_TRY(bunmpc::ik_launch_backward(a, st));
+        a.fwd_spec = active <= kSpecLineSearchBelow ? 1 : 0;
         HIP_TRY(bunmpc::ik_launch_forward(a, st));
         HIP_TRY(hipMemcpyAsync(&active, a.active, sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));

@@ -626,14 +626,22 @@ __global__ __launch_bounds__(64, 2) void ik_backward_kernel(const IkBatchArgs a)
 // and the base, one for the state cost, one for the control cost and the Euler step), and pieces with different code
 // cannot overlap inside a wave -- so a wave carries four independent chains through the same instruction stream.
 constexpr int kFwdSub = 4, kFwdLanes = 64 / kFwdSub;
+static_assert(kFwdSub == kTrySlots, "one trial slot per sub-group");
 
 struct FwdSub { double dx[kNDX], u[kNV], x[kNX], xn[kNX]; double part[kLegs + 1][10 + 3 * kFrameSlots]; double bc[4]; };
-struct ForwardLds { RobotModelDev m; FwdSub sub[kFwdSub]; };
+struct ForwardLds { RobotModelDev m; FwdSub sub[kFwdSub]; double vote[kFwdSub], ctry[kFwdSub]; };
 
+// Two mappings of the four sub-groups of a wave (a.fwd_spec, chosen by the host per DDP iteration):
+//   0  four PROBLEMS per wave, each trying its step lengths 2^-n one after the other (many active problems);
+//   1  four STEP LENGTHS of one problem per wave (2^-(4k+s) in round k): SolverDDP tries them in order and takes the
+//      first that passes, trials are independent of each other, so running them side by side and taking the first
+//      passing one is the same decision -- it trades idle SIMDs for a 4x shorter serial chain when few problems
+//      are still iterating.
 __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
     __shared__ ForwardLds s;
     const int lane = threadIdx.x, si = lane / kFwdLanes, l = lane % kFwdLanes;
-    const long b = (long)blockIdx.x * kFwdSub + si;
+    const bool spec = a.fwd_spec != 0;
+    const long b = spec ? (long)blockIdx.x : (long)blockIdx.x * kFwdSub + si;
     const bool pvalid = b < a.B;
     const long bb = pvalid ? b : 0;
     const IkLayout L = IkLayout::make(a.T);
@@ -643,6 +651,7 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
     bool live = pvalid && sc[S_DONE] == 0.0;     // this sub-group still has a line search to do
     if (!__any(live)) return;
     const int T = a.T, nn = a.T + 1;
+    const long xs_try = L.xs_try + (spec ? (long)si * nn * kNX : 0), us_try = L.us_try + (spec ? (long)si * T * kNV : 0);
     {   // the robot model is read many times per node: stage it in LDS once
         const int *src = reinterpret_cast<const int *>(a.model);
         int *dst = reinterpret_cast<int *>(&s.m);
@@ -656,13 +665,16 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
     const double *x_reg = a.x_reg + bb * kNX;
     const bool owner = live;            // sub-groups that take part at all
     bool accepted = false;
+    int win = 0;                        // trial slot holding the accepted trajectory
     double alpha = 1.0, cost_try = 0.0;
-    for (int ia = 0; ia < 10; ++ia) {   // alphas_ = 2^-n, n = 0..9; a sub-group that has accepted waits for the others
+    for (int round = 0; round < 10; ++round) {   // alphas_ = 2^-n, n = 0..9
         if (!__any(live)) break;
-        if (live) alpha = ldexp(1.0, -ia);
-        bool run = live;                // false once this trial has failed (tryStep threw)
+        const int ia = spec ? kFwdSub * round + si : round;
+        bool run = live && ia < 10;     // false once this trial has failed (tryStep threw) or there is no step length left
+        const double al = ldexp(1.0, -ia);
+        if (!spec && live) alpha = al;
         double ctry = 0.0;
-        if (run) { for (int i = l; i < kNX; i += kFwdLanes) q.x[i] = ws[L.xs_try + i]; }
+        if (run) { for (int i = l; i < kNX; i += kFwdLanes) q.x[i] = ws[L.xs_try + i]; }   // x0 sits in slot 0
         __syncthreads();
         for (int t = 0; t <= T; ++t) {   // t == T: terminal node (cost only)
             if (!__any(run)) break;
@@ -673,10 +685,10 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
                 if (run) {
                     for (int row = l; row < kNV; row += kFwdLanes) {
                         const double *Kr = ws + L.K + (long)t * kNV * kNDX + (long)row * kNDX;
-                        double v = ws[L.us + (long)t * kNV + row] - alpha * ws[L.kff + (long)t * kNV + row];
+                        double v = ws[L.us + (long)t * kNV + row] - al * ws[L.kff + (long)t * kNV + row];
                         UNROLL_RBD for (int j = 0; j < kNDX; ++j) v -= Kr[j] * q.dx[j];
                         q.u[row] = v;
-                        ws[L.us_try + (long)t * kNV + row] = v;
+                        ws[us_try + (long)t * kNV + row] = v;
                     }
                 }
                 __syncthreads();
@@ -709,7 +721,7 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
                     double xn[kNX];
                     euler_step<false>(q.x, q.u, dtn, xn, nullptr, nullptr);
                     bool bad = false;
-                    UNROLL_RBD for (int i = 0; i < kNX; ++i) { ws[L.xs_try + (long)(t + 1) * kNX + i] = xn[i]; q.xn[i] = xn[i]; bad = bad || !(fabs(xn[i]) < INFINITY); }
+                    UNROLL_RBD for (int i = 0; i < kNX; ++i) { ws[xs_try + (long)(t + 1) * kNX + i] = xn[i]; q.xn[i] = xn[i]; bad = bad || !(fabs(xn[i]) < INFINITY); }
                     q.bc[1] = bad ? 1.0 : 0.0;
                 } else q.bc[1] = 0.0;
                 q.bc[3] = tk.ctrl_w() * 0.5 * acc;
@@ -751,22 +763,37 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
             if (run) {
                 if (!terminal) { for (int i = l; i < kNX; i += kFwdLanes) q.x[i] = q.xn[i]; }
                 ctry += q.bc[0];
-                if (q.bc[1] != 0.0) run = false;       // tryStep threw: this sub-group goes on to the next step length
+                if (q.bc[1] != 0.0) run = false;       // tryStep threw: this step length is out
             }
             __syncthreads();
         }
-        if (live && run) {       // the trial ran to the end
-            cost_try = ctry;
-            const double dV = cost - cost_try;
-            const double dVexp = alpha * (d1 + 0.5 * alpha * d2);
-            if (dVexp >= 0.0 && (d1 < 1e-12 || !feas || dV > 0.1 * dVexp)) { accepted = true; live = false; }
+        bool pass = false;               // the trial ran to the end and passes SolverDDP's acceptance test
+        if (live && run) {
+            const double dV = cost - ctry;
+            const double dVexp = al * (d1 + 0.5 * al * d2);
+            pass = dVexp >= 0.0 && (d1 < 1e-12 || !feas || dV > 0.1 * dVexp);
+        }
+        if (!spec) {
+            if (pass) { accepted = true; live = false; cost_try = ctry; }
+        } else {
+            if (l == 0) { s.vote[si] = pass ? 1.0 : 0.0; s.ctry[si] = ctry; }
+            __syncthreads();
+            int w = -1;
+            UNROLL_RBD for (int k = kFwdSub - 1; k >= 0; --k) if (s.vote[k] != 0.0) w = k;    // first in SolverDDP's order
+            if (live) {
+                if (w >= 0) { accepted = true; win = w; alpha = ldexp(1.0, -(kFwdSub * round + w)); cost_try = s.ctry[w]; live = false; }
+                else if (kFwdSub * (round + 1) >= 10) { alpha = ldexp(1.0, -9); live = false; }   // every step length tried
+            }
+            __syncthreads();
         }
     }
     if (!owner) return;
     double xreg = sc[S_XREG];
     if (accepted) {   // setCandidate(xs_try, us_try, true)
-        for (long i = l; i < (long)nn * kNX; i += kFwdLanes) ws[L.xs + i] = ws[L.xs_try + i];
-        for (long i = l; i < (long)T * kNV; i += kFwdLanes) ws[L.us + i] = ws[L.us_try + i];
+        const long xsrc = L.xs_try + (long)win * nn * kNX, usrc = L.us_try + (long)win * T * kNV;
+        const int i0 = spec ? lane : l, step = spec ? 64 : kFwdLanes;
+        for (long i = i0; i < (long)nn * kNX; i += step) ws[L.xs + i] = i < kNX ? ws[L.xs_try + i] : ws[xsrc + i];
+        for (long i = i0; i < (long)T * kNV; i += step) ws[L.us + i] = ws[usrc + i];
     }
     if (alpha > 0.5) xreg = fmax(xreg / 10.0, 1e-9);          // decreaseRegularization
     bool done = false;
@@ -780,7 +807,7 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
     if (!done && wasfeas_new && sc[S_STOP] < 1e-9) { done = true; status = 0.0; }       // converged
     if (!done && iters >= (double)a.maxiter) { done = true; status = 1.0; }             // maxiter reached
     __builtin_amdgcn_wave_barrier();
-    if (l == 0) {
+    if (spec ? lane == 0 : l == 0) {
         if (accepted) { sc[S_WASFEAS] = feas ? 1.0 : 0.0; sc[S_FEAS] = 1.0; sc[S_COST] = cost_try; sc[S_RECALC] = 1.0; }
         else sc[S_RECALC] = 0.0;
         sc[S_XREG] = xreg; sc[S_ITERS] = iters;
@@ -849,7 +876,7 @@ hipError_t ik_launch_backward(const IkBatchArgs &a, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t ik_launch_forward(const IkBatchArgs &a, hipStream_t st) {
-    hipLaunchKernelGGL(ik_forward_kernel, dim3((a.B + 3) / 4), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(ik_forward_kernel, dim3(a.fwd_spec ? a.B : (a.B + 3) / 4), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 hipError_t ik_launch_centroidal_state(const RobotModelDev *model, const double *x, double *out9, int B, hipStream_t st) {

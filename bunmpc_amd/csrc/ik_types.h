@@ -35,6 +35,10 @@ struct RobotModelDev {
 //   state reg weight, ctrl reg weight                               -> 2
 constexpr int kNodeTaskDoubles = 5 * kFrameSlots + 4 + 7 + 2;
 
+// trial trajectories per problem: slot 0 is the one the sequential line search uses; the speculative line search
+// (four step lengths of one problem at once, ik_forward_kernel) fills all four
+constexpr int kTrySlots = 4;
+
 // Layout of the per-problem DDP workspace in HBM (doubles), T = number of running nodes.
 struct IkLayout {
     int T;
@@ -44,7 +48,7 @@ struct IkLayout {
         long o = 0;
         auto take = [&](long n) { long r = o; o += n; return r; };
         l.xs = take((long)(T + 1) * kNX); l.us = take((long)T * kNV);
-        l.xs_try = take((long)(T + 1) * kNX); l.us_try = take((long)T * kNV);
+        l.xs_try = take((long)kTrySlots * (T + 1) * kNX); l.us_try = take((long)kTrySlots * T * kNV);
         l.fs = take((long)(T + 1) * kNDX); l.xnext = take((long)T * kNX);
         l.Lx = take((long)(T + 1) * kNDX); l.Lxx = take((long)(T + 1) * kNDX * kNDX);
         l.Lu = take((long)T * kNV); l.Luu = take((long)T * kNV);
@@ -61,6 +65,7 @@ enum IkScal { S_COST = 0, S_XREG, S_D1, S_D2, S_STOP, S_FEAS, S_WASFEAS, S_DONE,
 
 struct IkBatchArgs {
     int B, T, maxiter;
+    int fwd_spec;              // forward pass: 1 = one problem per wave, four step lengths at once (few active problems)
     const RobotModelDev *model;
     const double *x0;          // [B][37]
     const double *dt;          // [B][T]

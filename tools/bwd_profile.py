@@ -11,7 +11,7 @@ for B in (1, 4096):
     kb = KinoDynDeviceBatch(wb, model, num_iters=10)
     kb.solve(); r = kb.results()
     T = wb.ik_T    # IkLayout::make (csrc/ik_types.h) up to the Quuk slot
-    o = sum([(T + 1) * 37, T * 18, (T + 1) * 37, T * 18, (T + 1) * 36, T * 37, (T + 1) * 36, (T + 1) * 1296, T * 18, T * 18,
+    o = sum([(T + 1) * 37, T * 18, 4 * (T + 1) * 37, 4 * T * 18, (T + 1) * 36, T * 37, (T + 1) * 36, (T + 1) * 1296, T * 18, T * 18,
              T * 36, T * 36, T * 648, T * 18, T * 18])
     ws = kb.ws.cpu().numpy()
     c = ws[:, o:o + 9] / wb.ik_T      # last backward pass only
