@@ -679,23 +679,22 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
         for (int t = 0; t <= T; ++t) {   // t == T: terminal node (cost only)
             if (!__any(run)) break;
             const bool terminal = t == T;
-            if (!terminal) {
-                if (run && l == 0) state_diff<false>(ws + L.xs + (long)t * kNX, q.x, q.dx, nullptr);
-                __syncthreads();
-                if (run) {
-                    for (int row = l; row < kNV; row += kFwdLanes) {
-                        const double *Kr = ws + L.K + (long)t * kNV * kNDX + (long)row * kNDX;
-                        double v = ws[L.us + (long)t * kNV + row] - al * ws[L.kff + (long)t * kNV + row];
-                        UNROLL_RBD for (int j = 0; j < kNDX; ++j) v -= Kr[j] * q.dx[j];
-                        q.u[row] = v;
-                        ws[us_try + (long)t * kNV + row] = v;
-                    }
-                }
-                __syncthreads();
-            }
-            // node evaluation spread over the sub-group's lanes: 0..3 legs, 4 base body, 5 state residual, 6 control cost + Euler step
             NodeTasks tk{a.tasks + (bb * nn + t) * kNodeTaskDoubles};
             const double dtn = terminal ? 0.0 : a.dt[bb * T + t];
+            // phase 1, lanes 0 and 5 in one instruction stream: dx = xs[t] (-) x (feeds the feedback) and the state
+            // regularisation residual x_reg (-) x (feeds the cost)
+            const bool want_dx = l == 0 && !terminal, want_rs = l == 5 && tk.state_w() != 0.0;
+            if (run && (want_dx || want_rs)) {
+                double d[kNDX];
+                state_diff<false>(want_dx ? ws + L.xs + (long)t * kNX : x_reg, q.x, d, nullptr);
+                if (want_dx) { UNROLL_RBD for (int i = 0; i < kNDX; ++i) q.dx[i] = d[i]; }
+                else {
+                    double acc = 0.0;
+                    UNROLL_RBD for (int i = 0; i < kNDX; ++i) acc += state_w[i] * d[i] * d[i];
+                    q.bc[2] = tk.state_w() * 0.5 * acc;
+                }
+            } else if (run && l == 5) q.bc[2] = 0.0;
+            // phase 2 (needs x only): legs on lanes 0..3, base body on lane 4
             if (run && l <= kLegs) {
                 int fid[kFrameSlots];
                 UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) fid[f] = tk.frame_w(f) != 0.0 ? tk.frame_id(f) : -1;
@@ -706,15 +705,20 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
                 UNROLL_RBD for (int c = 0; c < 6; ++c) q.part[l][4 + c] = ps.hO[c];
                 UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
                     UNROLL_RBD for (int c = 0; c < 3; ++c) q.part[l][10 + 3 * f + c] = ps.fhit[f] ? ps.fx[f][c] : 0.0;
-            } else if (run && l == 5) {
-                double acc = 0.0;
-                if (tk.state_w() != 0.0) {
-                    double rs[kNDX];
-                    state_diff<false>(x_reg, q.x, rs, nullptr);
-                    UNROLL_RBD for (int i = 0; i < kNDX; ++i) acc += state_w[i] * rs[i] * rs[i];
-                }
-                q.bc[2] = tk.state_w() * 0.5 * acc;
-            } else if (run && l == 6) {
+            }
+            __syncthreads();
+            // phase 3: feedback u = u - alpha k - K dx, two rows per lane (0..8 own rows l and l + 9), their 72 reads in flight together
+            if (run && !terminal && l < 9) {
+                const double *K0 = ws + L.K + (long)t * kNV * kNDX + (long)l * kNDX, *K1 = K0 + 9 * kNDX;
+                double v0 = ws[L.us + (long)t * kNV + l] - al * ws[L.kff + (long)t * kNV + l];
+                double v1 = ws[L.us + (long)t * kNV + l + 9] - al * ws[L.kff + (long)t * kNV + l + 9];
+                UNROLL_RBD for (int j = 0; j < kNDX; ++j) { v0 -= K0[j] * q.dx[j]; v1 -= K1[j] * q.dx[j]; }
+                q.u[l] = v0; q.u[l + 9] = v1;
+                ws[us_try + (long)t * kNV + l] = v0; ws[us_try + (long)t * kNV + l + 9] = v1;
+            }
+            __syncthreads();
+            // phase 4: control cost + Euler step (lane 6)
+            if (run && l == 6) {
                 double acc = 0.0;
                 if (!terminal) {
                     UNROLL_RBD for (int i = 0; i < kNV; ++i) acc += ctrl_w[i] * q.u[i] * q.u[i];
