@@ -422,7 +422,7 @@ __device__ __forceinline__ void apply_FxT(double (&x)[kNDX], unsigned a6_addr, u
     UNROLL_RBD for (int k = 6; k < kNV; ++k) x[kNV + k] = dt * x[k] + x[kNV + k];
 }
 
-__global__ __launch_bounds__(64, 2) void ik_backward_kernel(const IkBatchArgs a) {
+__global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
     __shared__ BackwardLds s;
     const long b = blockIdx.x;
     const int lane = threadIdx.x;
