@@ -492,6 +492,15 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
 #ifdef BWD_PROFILE
             pt0 = __builtin_readcyclecounter();
 #endif
+            // every global read of this node is issued here, so that the L_xx row (36 doubles per lane) travels while the
+            // F_x^T products and the transposition run
+            const double lx_t = row ? ws[L.Lx + (long)t * kNDX + r] : 0.0;
+            const double lu_t = ul ? ws[L.Lu + (long)t * kNV + uq] : 0.0, luu_t = ul ? ws[L.Luu + (long)t * kNV + uq] : 0.0;
+            double lr[kNDX];
+            {
+                const double *Lr = ws + L.Lxx + (long)t * kNDX * kNDX + (long)r * kNDX;
+                UNROLL_RBD for (int j = 0; j < kNDX; ++j) lr[j] = Lr[j];
+            }
             if (lane < 36) { s.A6[lane] = ws[L.A6 + (long)t * 36 + lane]; s.B6[lane] = ws[L.B6 + (long)t * 36 + lane]; }
             if (row) { s.Vx[r] = vx; s.fs[r] = ws[L.fs + (long)t * kNDX + r]; }
             __syncthreads();
@@ -509,16 +518,13 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             else if (r < kNV) fvx = s.Vx[r];
             else if (r < kNV + 6) { fvx = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) fvx += s.B6[6 * c + (r - kNV)] * s.Vx[c]; fvx = dt * fvx + s.Vx[r]; }
             else fvx = dt * s.Vx[r - kNV] + s.Vx[r];
-            const double qx = (row ? ws[L.Lx + (long)t * kNDX + r] : 0.0) + fvx;
-            const double qu = ul ? ws[L.Lu + (long)t * kNV + uq] + dt * fvx : 0.0;   // Q_u[q] on lane 18 + q
+            const double qx = lx_t + fvx;
+            const double qu = ul ? lu_t + dt * fvx : 0.0;   // Q_u[q] on lane 18 + q
             // Q_xu row; Q_uu row p on lane 18 + p (without its L_uu + reg diagonal term, kept in dgv); Q_xx row -> LDS
             double qxu[kNV], al[kNV];
             UNROLL_RBD for (int q = 0; q < kNV; ++q) { qxu[q] = dt * m[kNV + q]; al[q] = dt * qxu[q]; }
-            const double dgv = ul ? ws[L.Luu + (long)t * kNV + uq] + xreg : 0.0;
-            {
-                const double *Lr = ws + L.Lxx + (long)t * kNDX * kNDX + (long)r * kNDX;
-                if (row) { UNROLL_RBD for (int j = 0; j < kNDX; ++j) s.N[r * LD + j] = m[j] + Lr[j]; }
-            }
+            const double dgv = ul ? luu_t + xreg : 0.0;
+            if (row) { UNROLL_RBD for (int j = 0; j < kNDX; ++j) s.N[r * LD + j] = m[j] + lr[j]; }
             PSTAMPV(3, al[17])
             // Cholesky Q_uu = L L^T entirely in registers: lane 18 + p owns row p, the column entries and pivots
             // every lane needs travel by v_readlane (wave-uniform, no LDS, no waiting).  A non-positive or NaN
