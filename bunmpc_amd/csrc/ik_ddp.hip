@@ -574,16 +574,16 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             // against broadcast reads of K^T; unrolled over all j the scheduler hoists every read and spills)
             {
                 const unsigned kaddr = lds_offset(Ks);
-                for (int j0 = 0; j0 < kNDX; j0 += 2) {      // two columns per trip, their 18 K^T reads in flight together
-                    double2_t kk[18];
-                    lds_read_b128x18(kaddr + (unsigned)j0 * (kNV * 8), kk);
-                    const double2_t *k0 = kk, *k1 = kk + 9;
-                    double w0 = s.N[r * LD + j0], w1 = s.N[r * LD + j0 + 1];
+                for (int j0 = 0; j0 < kNDX; j0 += 4) {      // four columns per trip: their 36 K^T reads in two back-to-back batches
+                    double2_t ka[18], kb[18];
+                    lds_read_b128x18(kaddr + (unsigned)j0 * (kNV * 8), ka);
+                    lds_read_b128x18(kaddr + (unsigned)(j0 + 2) * (kNV * 8), kb);
+                    double w0 = s.N[r * LD + j0], w1 = s.N[r * LD + j0 + 1], w2 = s.N[r * LD + j0 + 2], w3 = s.N[r * LD + j0 + 3];
                     UNROLL_RBD for (int p = 0; p < 9; ++p) {
-                        w0 -= qxu[2 * p] * k0[p].x; w1 -= qxu[2 * p] * k1[p].x;
-                        w0 -= qxu[2 * p + 1] * k0[p].y; w1 -= qxu[2 * p + 1] * k1[p].y;
+                        w0 -= qxu[2 * p] * ka[p].x; w1 -= qxu[2 * p] * ka[9 + p].x; w2 -= qxu[2 * p] * kb[p].x; w3 -= qxu[2 * p] * kb[9 + p].x;
+                        w0 -= qxu[2 * p + 1] * ka[p].y; w1 -= qxu[2 * p + 1] * ka[9 + p].y; w2 -= qxu[2 * p + 1] * kb[p].y; w3 -= qxu[2 * p + 1] * kb[9 + p].y;
                     }
-                    if (row) { s.N[r * LD + j0] = w0; s.N[r * LD + j0 + 1] = w1; }
+                    if (row) { s.N[r * LD + j0] = w0; s.N[r * LD + j0 + 1] = w1; s.N[r * LD + j0 + 2] = w2; s.N[r * LD + j0 + 3] = w3; }
                 }
             }
             PSTAMPV(7, vx)
