@@ -634,7 +634,12 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
 constexpr int kFwdSub = 4, kFwdLanes = 64 / kFwdSub;
 static_assert(kFwdSub == kTrySlots, "one trial slot per sub-group");
 
-struct FwdSub { double dx[kNDX], u[kNV], x[kNX], xn[kNX]; double part[kLegs + 1][10 + 3 * kFrameSlots]; double bc[4]; };
+struct FwdSub {
+    double dx[kNDX], u[kNV], x[kNX], xn[kNX]; double part[kLegs + 1][10 + 3 * kFrameSlots]; double bc[4];
+    // copies of what every node reads from HBM: per problem (regularisation reference and weights), per node (task block,
+    // dt, the nominal state the feedback is taken around) -- the per-node ones are fetched one node ahead
+    double xreg[kNX], sw[kNDX], cw[kNV], tk[kNodeTaskDoubles + 1], xs[kNX];
+};
 struct ForwardLds { RobotModelDev m; FwdSub sub[kFwdSub]; double vote[kFwdSub], ctry[kFwdSub]; };
 
 // Two mappings of the four sub-groups of a wave (a.fwd_spec, chosen by the host per DDP iteration):
@@ -663,12 +668,18 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
         int *dst = reinterpret_cast<int *>(&s.m);
         for (int i = lane; i < (int)(sizeof(RobotModelDev) / sizeof(int)); i += 64) dst[i] = src[i];
     }
+    if (live) {
+        const double *gsw = batch_ptr(a.state_w, a.s_state_w, bb), *gcw = batch_ptr(a.ctrl_w, a.s_ctrl_w, bb), *gxr = a.x_reg + bb * kNX;
+        for (int i = l; i < kNX; i += kFwdLanes) q.xreg[i] = gxr[i];
+        for (int i = l; i < kNDX; i += kFwdLanes) q.sw[i] = gsw[i];
+        for (int i = l; i < kNV; i += kFwdLanes) q.cw[i] = gcw[i];
+    }
     __syncthreads();
     const RobotModelDev &m = s.m;
     const double cost = sc[S_COST], d1 = sc[S_D1], d2 = sc[S_D2];
     const bool feas = sc[S_FEAS] != 0.0;
-    const double *state_w = batch_ptr(a.state_w, a.s_state_w, bb), *ctrl_w = batch_ptr(a.ctrl_w, a.s_ctrl_w, bb);
-    const double *x_reg = a.x_reg + bb * kNX;
+    const double *state_w = q.sw, *ctrl_w = q.cw, *x_reg = q.xreg;
+    const double *gtasks = a.tasks + bb * nn * kNodeTaskDoubles, *gdt = a.dt + bb * T;
     const bool owner = live;            // sub-groups that take part at all
     bool accepted = false;
     int win = 0;                        // trial slot holding the accepted trajectory
@@ -680,19 +691,41 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
         const double al = ldexp(1.0, -ia);
         if (!spec && live) alpha = al;
         double ctry = 0.0;
-        if (run) { for (int i = l; i < kNX; i += kFwdLanes) q.x[i] = ws[L.xs_try + i]; }   // x0 sits in slot 0
+        if (run) {
+            for (int i = l; i < kNX; i += kFwdLanes) { q.x[i] = ws[L.xs_try + i]; q.xs[i] = ws[L.xs + i]; }   // x0 sits in slot 0
+            for (int i = l; i < kNodeTaskDoubles; i += kFwdLanes) q.tk[i] = gtasks[i];
+            if (l == 0) q.tk[kNodeTaskDoubles] = gdt[0];
+        }
+        // feedback rows of node 0 (lanes 0..8 own rows l and l + 9): fetched one node ahead of their use from here on
+        double kp0[kNDX], kp1[kNDX], up0 = 0.0, up1 = 0.0, fp0 = 0.0, fp1 = 0.0;
+        if (run && l < 9) {
+            const double *K0 = ws + L.K + (long)l * kNDX, *K1 = K0 + 9 * kNDX;
+            UNROLL_RBD for (int j = 0; j < kNDX; ++j) { kp0[j] = K0[j]; kp1[j] = K1[j]; }
+            up0 = ws[L.us + l]; up1 = ws[L.us + l + 9]; fp0 = ws[L.kff + l]; fp1 = ws[L.kff + l + 9];
+        }
         __syncthreads();
         for (int t = 0; t <= T; ++t) {   // t == T: terminal node (cost only)
             if (!__any(run)) break;
             const bool terminal = t == T;
-            NodeTasks tk{a.tasks + (bb * nn + t) * kNodeTaskDoubles};
-            const double dtn = terminal ? 0.0 : a.dt[bb * T + t];
+            NodeTasks tk{q.tk};
+            const double dtn = terminal ? 0.0 : q.tk[kNodeTaskDoubles];
+            // next node's task block / dt / nominal state: requested now, parked in LDS at the end of this node
+            double ntk[3] = {0.0, 0.0, 0.0}, nxs[3] = {0.0, 0.0, 0.0};
+            if (run && !terminal) {
+                const double *g = gtasks + (long)(t + 1) * kNodeTaskDoubles;
+                UNROLL_RBD for (int k = 0; k < 3; ++k) {
+                    const int i = l + kFwdLanes * k;
+                    if (i < kNodeTaskDoubles) ntk[k] = g[i];
+                    else if (i == kNodeTaskDoubles) ntk[k] = t + 1 < T ? gdt[t + 1] : 0.0;
+                    if (i < kNX) nxs[k] = ws[L.xs + (long)(t + 1) * kNX + i];
+                }
+            }
             // phase 1, lanes 0 and 5 in one instruction stream: dx = xs[t] (-) x (feeds the feedback) and the state
             // regularisation residual x_reg (-) x (feeds the cost)
             const bool want_dx = l == 0 && !terminal, want_rs = l == 5 && tk.state_w() != 0.0;
             if (run && (want_dx || want_rs)) {
                 double d[kNDX];
-                state_diff<false>(want_dx ? ws + L.xs + (long)t * kNX : x_reg, q.x, d, nullptr);
+                state_diff<false>(want_dx ? q.xs : x_reg, q.x, d, nullptr);
                 if (want_dx) { UNROLL_RBD for (int i = 0; i < kNDX; ++i) q.dx[i] = d[i]; }
                 else {
                     double acc = 0.0;
@@ -715,12 +748,16 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
             __syncthreads();
             // phase 3: feedback u = u - alpha k - K dx, two rows per lane (0..8 own rows l and l + 9), their 72 reads in flight together
             if (run && !terminal && l < 9) {
-                const double *K0 = ws + L.K + (long)t * kNV * kNDX + (long)l * kNDX, *K1 = K0 + 9 * kNDX;
-                double v0 = ws[L.us + (long)t * kNV + l] - al * ws[L.kff + (long)t * kNV + l];
-                double v1 = ws[L.us + (long)t * kNV + l + 9] - al * ws[L.kff + (long)t * kNV + l + 9];
-                UNROLL_RBD for (int j = 0; j < kNDX; ++j) { v0 -= K0[j] * q.dx[j]; v1 -= K1[j] * q.dx[j]; }
+                double v0 = up0 - al * fp0, v1 = up1 - al * fp1;
+                UNROLL_RBD for (int j = 0; j < kNDX; ++j) { v0 -= kp0[j] * q.dx[j]; v1 -= kp1[j] * q.dx[j]; }
                 q.u[l] = v0; q.u[l + 9] = v1;
                 ws[us_try + (long)t * kNV + l] = v0; ws[us_try + (long)t * kNV + l + 9] = v1;
+                if (t + 1 < T) {   // rows of the next node travel while this node is evaluated
+                    const double *K0 = ws + L.K + (long)(t + 1) * kNV * kNDX + (long)l * kNDX, *K1 = K0 + 9 * kNDX;
+                    UNROLL_RBD for (int j = 0; j < kNDX; ++j) { kp0[j] = K0[j]; kp1[j] = K1[j]; }
+                    up0 = ws[L.us + (long)(t + 1) * kNV + l]; up1 = ws[L.us + (long)(t + 1) * kNV + l + 9];
+                    fp0 = ws[L.kff + (long)(t + 1) * kNV + l]; fp1 = ws[L.kff + (long)(t + 1) * kNV + l + 9];
+                }
             }
             __syncthreads();
             // phase 4: control cost + Euler step (lane 6)
@@ -771,7 +808,14 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
             }
             __syncthreads();
             if (run) {
-                if (!terminal) { for (int i = l; i < kNX; i += kFwdLanes) q.x[i] = q.xn[i]; }
+                if (!terminal) {
+                    for (int i = l; i < kNX; i += kFwdLanes) q.x[i] = q.xn[i];
+                    UNROLL_RBD for (int k = 0; k < 3; ++k) {
+                        const int i = l + kFwdLanes * k;
+                        if (i <= kNodeTaskDoubles) q.tk[i] = ntk[k];
+                        if (i < kNX) q.xs[i] = nxs[k];
+                    }
+                }
                 ctry += q.bc[0];
                 if (q.bc[1] != 0.0) run = false;       // tryStep threw: this step length is out
             }
