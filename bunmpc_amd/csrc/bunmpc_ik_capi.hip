@@ -211,6 +211,10 @@ bmpc_model_t *bmpc_model_create(int nj, const int *parent, const double *R, cons
         const double *I = inertia + 9 * b;
         h.inertia[b][0] = I[0]; h.inertia[b][1] = I[1]; h.inertia[b][2] = I[2];
         h.inertia[b][3] = I[4]; h.inertia[b][4] = I[5]; h.inertia[b][5] = I[8];
+        double *r = h.rec[b];
+        for (int c = 0; c < 3; ++c) { r[c] = b > 0 ? h.p[b - 1][c] : 0.0; r[3 + c] = b > 0 ? h.axis[b - 1][c] : 0.0; r[7 + c] = h.com[b][c]; }
+        r[6] = h.mass[b];
+        for (int c = 0; c < 6; ++c) r[10 + c] = h.inertia[b][c];
     }
     for (int f = 0; f < nframes; ++f) {
         if (frame_body[f] < 0 || frame_body[f] > nj) { delete m; ik_fail(BMPC_BAD_ARG, "frame body out of range"); return nullptr; }

@@ -16,7 +16,10 @@ constexpr int kNV = 18, kNQ = 19, kNX = 37, kNDX = 36;   // the kernels are buil
 constexpr int kFrameSlots = 4;   // frame-translation tasks per node (the harness adds <= n_eff)
 
 // Rigid-body model (device copy).  Body 0 = base, body i+1 = joint i.
-struct RobotModelDev {
+struct alignas(16) RobotModelDev {
+    // one packed record per body for the kernels' batched reads (rbd_quad.h::load_body): [joint placement p (3) |
+    // axis (3) | mass | com (3) | inertia xx xy xz yy yz zz (6)] = 16 doubles; body 0 (base) has no joint
+    double rec[kMaxJoints + 1][16];
     int nj, nframes;
     int parent[kMaxJoints];          // -1 = base, else joint index
     int chain_end[kMaxJoints];       // last joint of the serial chain joint i belongs to

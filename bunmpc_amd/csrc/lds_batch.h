@@ -22,6 +22,12 @@ __device__ __forceinline__ void lds_read_b128x3(unsigned addr, double2_t (&o)[3]
                  : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2])
                  : "v"(addr) : "memory");
 }
+// 8 x 16 bytes (16 doubles) from a 16-byte aligned address
+__device__ __forceinline__ void lds_read_b128x8(unsigned addr, double2_t (&o)[8]) {
+    asm volatile("ds_read_b128 %0, %8 offset:0\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\tds_read_b128 %3, %8 offset:48\n\tds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\tds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112\n\t" "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+                 : "v"(addr) : "memory");
+}
 // 11 x 16 bytes (22 doubles) from a 16-byte aligned address
 __device__ __forceinline__ void lds_read_b128x11(unsigned addr, double2_t (&o)[11]) {
     asm volatile("ds_read_b128 %0, %11 offset:0\n\tds_read_b128 %1, %11 offset:16\n\tds_read_b128 %2, %11 offset:32\n\tds_read_b128 %3, %11 offset:48\n\tds_read_b128 %4, %11 offset:64\n\tds_read_b128 %5, %11 offset:80\n\tds_read_b128 %6, %11 offset:96\n\tds_read_b128 %7, %11 offset:112\n\tds_read_b128 %8, %11 offset:128\n\tds_read_b128 %9, %11 offset:144\n\tds_read_b128 %10, %11 offset:160\n\t" "s_waitcnt lgkmcnt(0)"

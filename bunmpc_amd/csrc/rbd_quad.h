@@ -8,6 +8,7 @@
 //                          dh_g/dq column (d h_O/dq = S x* h_sub - I_sub (S x V_parent))
 #pragma once
 #include "rbd_device.h"
+#include "lds_batch.h"
 
 #define UNROLL_RBD _Pragma("unroll")
 
@@ -78,6 +79,68 @@ RBD_D void joint_step(const RobotModelDev &m, int i, double qi, double vi, const
     mat3vec(Rp, m.p[i], t);
     UNROLL_RBD for (int c = 0; c < 3; ++c) p[c] = t[c] + pp[c];
     mat3vec(R, m.axis[i], S + 3);
+    cross3(p, S + 3, S);
+    UNROLL_RBD for (int c = 0; c < 6; ++c) V[c] = Vp[c] + S[c] * vi;
+}
+
+// ---- body constants in registers: one batched LDS read per body instead of ~16 scattered ones (the kernels keep the
+// model in LDS; hipcc glues each scattered ds_read to its first use, one exposed latency apiece)
+struct BodyRec { double p[3], axis[3], mass, com[3], I[6]; };
+
+RBD_D void load_body(const RobotModelDev &m, int b, BodyRec &o) {   // m must live in LDS
+    double2_t t[8];
+    lds_read_b128x8(lds_offset(m.rec[b]), t);
+    o.p[0] = t[0].x; o.p[1] = t[0].y; o.p[2] = t[1].x; o.axis[0] = t[1].y; o.axis[1] = t[2].x; o.axis[2] = t[2].y;
+    o.mass = t[3].x; o.com[0] = t[3].y; o.com[1] = t[4].x; o.com[2] = t[4].y;
+    o.I[0] = t[5].x; o.I[1] = t[5].y; o.I[2] = t[6].x; o.I[3] = t[6].y; o.I[4] = t[7].x; o.I[5] = t[7].y;
+}
+
+RBD_D void body_momentum_r(const BodyRec &br, const double *R, const double *p, const double *V, double &mass, double *h1, double *h) {
+    double cw[3], t[3], wl[3], Iw[3], n[3];
+    mat3vec(R, br.com, cw);
+    UNROLL_RBD for (int c = 0; c < 3; ++c) cw[c] += p[c];
+    const double mb = br.mass;
+    cross3(V + 3, cw, t);
+    double l[3];
+    UNROLL_RBD for (int c = 0; c < 3; ++c) l[c] = mb * (V[c] + t[c]);
+    mat3Tvec(R, V + 3, wl);
+    const double *I = br.I;
+    Iw[0] = I[0] * wl[0] + I[1] * wl[1] + I[2] * wl[2];
+    Iw[1] = I[1] * wl[0] + I[3] * wl[1] + I[4] * wl[2];
+    Iw[2] = I[2] * wl[0] + I[4] * wl[1] + I[5] * wl[2];
+    mat3vec(R, Iw, n);
+    cross3(cw, l, t);
+    mass += mb;
+    UNROLL_RBD for (int c = 0; c < 3; ++c) { h1[c] += mb * cw[c]; h[c] += l[c]; h[3 + c] += n[c] + t[c]; }
+}
+
+template <bool VEL>
+RBD_D void body_terms_r(const BodyRec &br, const double *R, const double *p, const double *V, BodyAcc &o) {
+    double cw[3], RI[9], Iw[9];
+    mat3vec(R, br.com, cw);
+    UNROLL_RBD for (int c = 0; c < 3; ++c) cw[c] += p[c];
+    const double I[9] = {br.I[0], br.I[1], br.I[2], br.I[1], br.I[3], br.I[4], br.I[2], br.I[4], br.I[5]};
+    mat3mul(R, I, RI);
+    UNROLL_RBD for (int i = 0; i < 3; ++i)
+        UNROLL_RBD for (int j = 0; j < 3; ++j)
+            Iw[3 * i + j] = RI[3 * i] * R[3 * j] + RI[3 * i + 1] * R[3 * j + 1] + RI[3 * i + 2] * R[3 * j + 2];
+    const double mb = br.mass, cc = dot3(cw, cw);
+    o.c.m = mb;
+    UNROLL_RBD for (int c = 0; c < 3; ++c) o.c.h1[c] = mb * cw[c];
+    o.c.I[0] = Iw[0] + mb * (cc - cw[0] * cw[0]); o.c.I[1] = Iw[1] - mb * cw[0] * cw[1]; o.c.I[2] = Iw[2] - mb * cw[0] * cw[2];
+    o.c.I[3] = Iw[4] + mb * (cc - cw[1] * cw[1]); o.c.I[4] = Iw[5] - mb * cw[1] * cw[2]; o.c.I[5] = Iw[8] + mb * (cc - cw[2] * cw[2]);
+    if (VEL) comp_apply(o.c, V, o.h);
+}
+
+RBD_D void joint_step_r(const RobotModelDev &m, const BodyRec &br, int i, double qi, double vi, const double *Rp, const double *pp,
+                        const double *Vp, double *R, double *p, double *S, double *V) {
+    double Rq[9], t[3];
+    rodrigues(br.axis, qi, Rq);
+    if (m.R_identity[i]) mat3mul(Rp, Rq, R);
+    else { double Rl[9]; mat3mul(m.R[i], Rq, Rl); mat3mul(Rp, Rl, R); }
+    mat3vec(Rp, br.p, t);
+    UNROLL_RBD for (int c = 0; c < 3; ++c) p[c] = t[c] + pp[c];
+    mat3vec(R, br.axis, S + 3);
     cross3(p, S + 3, S);
     UNROLL_RBD for (int c = 0; c < 6; ++c) V[c] = Vp[c] + S[c] * vi;
 }
@@ -183,8 +246,10 @@ RBD_D void quad_part(const RobotModelDev &m, const double *x, const int *fid, in
                 o.fhit[s] = 1;
             }
     };
+    BodyRec br;
     if (part == kLegs) {
-        body_momentum(m, 0, Rb, pb, Vb, o.mass, o.h1, o.hO);
+        load_body(m, 0, br);
+        body_momentum_r(br, Rb, pb, Vb, o.mass, o.h1, o.hO);
         frames_on(0, Rb, pb);
         return;
     }
@@ -195,8 +260,9 @@ RBD_D void quad_part(const RobotModelDev &m, const double *x, const int *fid, in
     UNROLL_RBD for (int j = 0; j < kLegJoints; ++j) {
         const int i = kLegJoints * part + j;      // runtime leg: model / state reads are indexed, locals are not
         double R[9], p[3], S[6], V[6];
-        joint_step(m, i, x[7 + i], v[6 + i], Rp, pp, Vp, R, p, S, V);
-        body_momentum(m, i + 1, R, p, V, o.mass, o.h1, o.hO);
+        load_body(m, i + 1, br);
+        joint_step_r(m, br, i, x[7 + i], v[6 + i], Rp, pp, Vp, R, p, S, V);
+        body_momentum_r(br, R, p, V, o.mass, o.h1, o.hO);
         frames_on(i + 1, R, p);
         UNROLL_RBD for (int c = 0; c < 9; ++c) Rp[c] = R[c];
         UNROLL_RBD for (int c = 0; c < 3; ++c) pp[c] = p[c];
@@ -293,8 +359,10 @@ RBD_D void quad_part_walk(const RobotModelDev &m, const double *x, const int *fi
             }
     };
     BodyAcc ba;
+    BodyRec br;
     if (col < 6) {
-        body_terms<true>(m, 0, Rb, pb, Vb, ba);
+        load_body(m, 0, br);
+        body_terms_r<true>(br, Rb, pb, Vb, ba);
         o.part = ba.c;
         UNROLL_RBD for (int c = 0; c < 6; ++c) { o.hpart[c] = ba.h[c]; o.Vpar[c] = 0.0; }
         frames_on(0, Rb, pb);
@@ -314,8 +382,9 @@ RBD_D void quad_part_walk(const RobotModelDev &m, const double *x, const int *fi
     UNROLL_RBD for (int j = 0; j < kLegJoints; ++j) {
         const int i = kLegJoints * L + j;
         double R[9], p[3], S[6], V[6];
-        joint_step(m, i, x[7 + i], v[6 + i], Rp, pp, Vp, R, p, S, V);
-        body_terms<true>(m, i + 1, R, p, V, ba);
+        load_body(m, i + 1, br);
+        joint_step_r(m, br, i, x[7 + i], v[6 + i], Rp, pp, Vp, R, p, S, V);
+        body_terms_r<true>(br, R, p, V, ba);
         comp_add(o.part, ba.c);
         UNROLL_RBD for (int c = 0; c < 6; ++c) o.hpart[c] += ba.h[c];
         if (j == jsel) { UNROLL_RBD for (int c = 0; c < 6; ++c) { o.S[c] = S[c]; o.Vpar[c] = Vp[c]; } }
