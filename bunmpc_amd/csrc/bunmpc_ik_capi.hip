@@ -147,9 +147,22 @@ bunmpc::IkBatchArgs make_args(int B, int T, int maxiter, const bmpc_model *model
 // problem: 1024 SIMDs on an MI355X)
 constexpr int kSpecLineSearchBelow = 1024;
 
+// one host-mapped word per host thread, through which the kernels' active counter reaches the DDP loop
+struct ActiveWord {
+    int *host = nullptr, *dev = nullptr;
+    int ensure() {
+        if (host) return BMPC_OK;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&host), sizeof(int), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&dev), host, 0));
+        return BMPC_OK;
+    }
+};
+thread_local ActiveWord g_active_word;
+
 int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run) {
     bunmpc::IkBatchArgs a = a0;
     a.fwd_spec = 0;
+    if (int rc = g_active_word.ensure()) return rc;
     HIP_TRY(bunmpc::ik_launch_init(a, st));
     int active = a.B, it = 0;
     for (; it < a.maxiter && active > 0; ++it) {
@@ -157,8 +170,9 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run) {
         HIP_TRY(bunmpc::ik_launch_backward(a, st));
         a.fwd_spec = active <= kSpecLineSearchBelow ? 1 : 0;
         HIP_TRY(bunmpc::ik_launch_forward(a, st));
-        HIP_TRY(hipMemcpyAsync(&active, a.active, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(bunmpc::ik_launch_publish_active(a.active, g_active_word.dev, st));
         HIP_TRY(hipStreamSynchronize(st));
+        active = *static_cast<volatile int *>(g_active_word.host);
     }
     if (iters_run) *iters_run = it;
     return BMPC_OK;

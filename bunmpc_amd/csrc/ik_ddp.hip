@@ -893,6 +893,13 @@ __global__ void ik_com_mom_kernel(const RobotModelDev *model, const double *xs, 
     for (int c = 0; c < 6; ++c) mom[i * 6 + c] = p1.hg[c];
 }
 
+// the active-problem counter, copied to a host-mapped word: the host reads it after its stream synchronisation
+// without a device-to-host copy operation (a 4-byte hipMemcpy into pageable memory costs ~50 us per DDP iteration)
+__global__ void ik_publish_active_kernel(const int *active, volatile int *host_word) {
+    *host_word = *active;
+    __threadfence_system();
+}
+
 // com / momentum references of the IK tracking tasks from the centroidal solution X
 // (KinoDynMP::optimize, kino_dyn.cpp:50-56: rows 0..T-1 running, row T terminal; mom = [m v, L])
 __global__ void kd_fill_refs_kernel(double *tasks, const double *X, double m, int B, int H, int T) {
@@ -914,6 +921,10 @@ __global__ void kd_fill_refs_kernel(double *tasks, const double *X, double m, in
 hipError_t ik_launch_fill_refs(double *tasks, const double *X, double m, int B, int H, int T, hipStream_t st) {
     const long n = (long)B * (T + 1);
     hipLaunchKernelGGL(kd_fill_refs_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, tasks, X, m, B, H, T);
+    return hipGetLastError();
+}
+hipError_t ik_launch_publish_active(const int *active, int *host_word_dev, hipStream_t st) {
+    hipLaunchKernelGGL(ik_publish_active_kernel, dim3(1), dim3(1), 0, st, active, host_word_dev);
     return hipGetLastError();
 }
 hipError_t ik_launch_init(const IkBatchArgs &a, hipStream_t st) {

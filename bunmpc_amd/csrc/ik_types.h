@@ -85,6 +85,8 @@ hipError_t ik_launch_init(const IkBatchArgs &a, hipStream_t s);
 hipError_t ik_launch_calcdiff(const IkBatchArgs &a, hipStream_t s);
 hipError_t ik_launch_backward(const IkBatchArgs &a, hipStream_t s);
 hipError_t ik_launch_forward(const IkBatchArgs &a, hipStream_t s);
+// *host_word_dev (device alias of a host-mapped int) = *active
+hipError_t ik_launch_publish_active(const int *active, int *host_word_dev, hipStream_t s);
 // centroidal state [com, vcom, L] (9) of (q, v): KinoDynMP::optimize's x0 (kino_dyn.cpp:42,86-97)
 hipError_t ik_launch_centroidal_state(const RobotModelDev *model, const double *x, double *out9, int B, hipStream_t s);
 // com (3) and h_g (6) along a state trajectory [B][n][37]  (InverseKinematics::return_opt_com/mom)
