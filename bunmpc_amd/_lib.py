@@ -107,6 +107,7 @@ _SIGS = {
     "bmpc_biconvex_solve_batch_host": (_I, [_P]),
     "bmpc_biconvex_kernel_name": (C.c_char_p, [_I, _I]),
     "bmpc_plan_batch_device": (_I, [_P, _P]),
+    "bmpc_ik_set_speculative_below": (_I, [_I]),
     "bmpc_model_create": (_P, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "bmpc_model_destroy": (None, [_P]),
     "bmpc_model_total_mass": (_D, [_P]),

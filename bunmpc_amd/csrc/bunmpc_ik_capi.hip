@@ -145,7 +145,7 @@ bunmpc::IkBatchArgs make_args(int B, int T, int maxiter, const bmpc_model *model
 // the DDP iteration loop (SolverDDP::solve): three launches per iteration, stop when every problem is done
 // below this many active problems the forward pass runs four step lengths of a problem side by side (one wave per
 // problem: 1024 SIMDs on an MI355X)
-constexpr int kSpecLineSearchBelow = 1024;
+int g_spec_line_search_below = 1024;
 
 // one host-mapped word per host thread, through which the kernels' active counter reaches the DDP loop
 struct ActiveWord {
@@ -168,7 +168,7 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run) {
     for (; it < a.maxiter && active > 0; ++it) {
         HIP_TRY(bunmpc::ik_launch_calcdiff(a, st));
         HIP_TRY(bunmpc::ik_launch_backward(a, st));
-        a.fwd_spec = active <= kSpecLineSearchBelow ? 1 : 0;
+        a.fwd_spec = active <= g_spec_line_search_below ? 1 : 0;
         HIP_TRY(bunmpc::ik_launch_forward(a, st));
         HIP_TRY(bunmpc::ik_launch_publish_active(a.active, g_active_word.dev, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -238,6 +238,7 @@ bmpc_model_t *bmpc_model_create(int nj, const int *parent, const double *R, cons
     return m;
 }
 void bmpc_model_destroy(bmpc_model_t *m) { delete m; }
+int bmpc_ik_set_speculative_below(int n_active) { const int old = g_spec_line_search_below; g_spec_line_search_below = n_active; return old; }
 double bmpc_model_total_mass(const bmpc_model_t *m) { return m ? m->host.total_mass : 0.0; }
 
 // ----------------------------------------------------------- InverseKinematics ----

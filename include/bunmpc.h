@@ -209,7 +209,11 @@ typedef struct {
     int *iters_run;   /* host int or NULL: DDP iterations the loop executed */
 } bmpc_ik_batch_t;
 int bmpc_ik_workspace_doubles(int n_col);
-void bmpc_ik_layout(int n_col, long *offsets8);   /* xs, us, scalars, K, k, fs, Lx, Lxx */
+void bmpc_ik_layout(int n_col, long *offsets8);
+/* Line-search scheduling of the batched DDP (no effect on results): while at most n_active problems are still
+ * iterating, four step lengths of a problem are tried side by side (one wave per problem) instead of one after the
+ * other (four problems per wave).  Default 1024 (one wave per SIMD of an MI355X); 0 = never.  Returns the old value. */
+int bmpc_ik_set_speculative_below(int n_active);   /* xs, us, scalars, K, k, fs, Lx, Lxx */
 int bmpc_ik_solve_batch_device(const bmpc_ik_batch_t *d, void *hip_stream);
 /* [com, vcom, hg.angular] of x = [q, v]: what KinoDynMP::optimize feeds the centroidal solve (kino_dyn.cpp:42,86-97) */
 int bmpc_ik_centroidal_state_device(const bmpc_model_t *model, const double *x, double *out9, int B, void *hip_stream);

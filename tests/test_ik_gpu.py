@@ -200,3 +200,24 @@ def test_kinodyn_batch_go2_h60(oracle):
         assert abs(got["ik_cost"][i] - r["cost"]) <= 1e-7 * abs(r["cost"])
         assert rel_l2(got["xs"][i].reshape(-1), np.array(r["xs"]).reshape(-1)) < 1e-6
     print("go2 ik iters", got["ik_iters"], "rel X", rel_l2(got["X"], ref["X"]))
+
+
+def test_line_search_scheduling_does_not_change_results(model):
+    """the forward pass tries step lengths one after the other (four problems per wave) or four at a time (one problem
+    per wave); SolverDDP's decision -- the first passing step length in its order -- is the same either way"""
+    from bunmpc_amd import _lib
+    from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
+    wb = problems.make_wb_batch(model, 9)
+    out = []
+    old = _lib.lib().bmpc_ik_set_speculative_below(0)
+    try:
+        for below in (0, 1 << 30):
+            _lib.lib().bmpc_ik_set_speculative_below(below)
+            kb = KinoDynDeviceBatch(wb, model, num_iters=10)
+            kb.solve()
+            out.append(kb.results())
+    finally:
+        _lib.lib().bmpc_ik_set_speculative_below(old)
+    assert np.array_equal(out[0]["ik_iters"], out[1]["ik_iters"]) and np.all(out[0]["ik_status"] == 0)
+    assert np.array_equal(out[0]["xs"], out[1]["xs"]) and np.array_equal(out[0]["us"], out[1]["us"])
+    assert np.array_equal(out[0]["ik_cost"], out[1]["ik_cost"])
