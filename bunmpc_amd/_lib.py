@@ -44,6 +44,15 @@ class PlanBatch(C.Structure):
                                            "hip_off", "cnt_plan", "swing_time", "dt", "X_nom", "X_ter")])
 
 
+class WbPlanBatch(C.Structure):
+    """bmpc_wb_plan_batch_t"""
+    _fields_ = ([("B", C.c_int), ("n_col", C.c_int), ("ik_col", C.c_int), ("reserved_", C.c_int), ("model", C.c_void_p),
+                 ("gait", C.c_void_p), ("foot_frame", C.c_int * 4), ("step_ht", C.c_double), ("swing_wt", C.c_double * 2),
+                 ("cent_wt", C.c_double * 2), ("reg_wt", C.c_double * 2)] +
+                [(n, C.c_void_p) for n in ("x", "t0", "v_des_body", "com", "feet0", "v_des", "w_des", "hip_off", "amom", "x_init",
+                                           "cnt_plan", "swing_time", "dt", "X_nom", "X_ter", "ik_tasks")])
+
+
 _lib = None
 
 _D = C.c_double
@@ -107,6 +116,7 @@ _SIGS = {
     "bmpc_biconvex_solve_batch_host": (_I, [_P]),
     "bmpc_biconvex_kernel_name": (C.c_char_p, [_I, _I]),
     "bmpc_plan_batch_device": (_I, [_P, _P]),
+    "bmpc_wb_plan_batch_device": (_I, [_P, _P]),
     "bmpc_ik_set_speculative_below": (_I, [_I]),
     "bmpc_model_create": (_P, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "bmpc_model_destroy": (None, [_P]),

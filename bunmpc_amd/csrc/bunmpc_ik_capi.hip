@@ -4,6 +4,10 @@
 #include "../../include/bunmpc.h"
 #include "ik_types.h"
 
+namespace bunmpc {
+int launch_wb_plan(const RobotModelDev *model, const bmpc_wb_plan_batch_t &d, hipStream_t st);   // plan_gen.hip
+}
+
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -238,6 +242,21 @@ bmpc_model_t *bmpc_model_create(int nj, const int *parent, const double *R, cons
     return m;
 }
 void bmpc_model_destroy(bmpc_model_t *m) { delete m; }
+
+int bmpc_wb_plan_batch_device(const bmpc_wb_plan_batch_t *d, void *hip_stream) {
+    if (!d || !d->model) return ik_fail(BMPC_BAD_ARG, "null descriptor or model");
+    if (d->B < 0 || d->n_col < 1 || d->ik_col < 1 || d->ik_col > d->n_col) return ik_fail(BMPC_BAD_ARG, "bad sizes");
+    if (!d->gait || !d->x || !d->t0 || !d->v_des_body) return ik_fail(BMPC_BAD_ARG, "missing input array");
+    if (!d->com || !d->feet0 || !d->v_des || !d->w_des || !d->hip_off || !d->amom || !d->x_init || !d->cnt_plan || !d->swing_time ||
+        !d->dt || !d->X_nom || !d->X_ter || !d->ik_tasks)
+        return ik_fail(BMPC_BAD_ARG, "missing output array");
+    for (int j = 0; j < 4; ++j)
+        if (d->foot_frame[j] < 0 || d->foot_frame[j] >= d->model->host.nframes) return ik_fail(BMPC_BAD_ARG, "foot frame out of range");
+    if (d->B == 0) return BMPC_OK;
+    bmpc_model *m = const_cast<bmpc_model *>(d->model);
+    if (int rc = m->upload()) return rc;
+    return bunmpc::launch_wb_plan(m->dptr(), *d, static_cast<hipStream_t>(hip_stream));
+}
 int bmpc_ik_set_speculative_below(int n_active) { const int old = g_spec_line_search_below; g_spec_line_search_below = n_active; return old; }
 double bmpc_model_total_mass(const bmpc_model_t *m) { return m ? m->host.total_mass : 0.0; }
 

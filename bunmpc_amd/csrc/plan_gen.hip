@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/bunmpc.h"
+#include "ik_types.h"
+#include "rbd_quad.h"
 
 // bit-for-bit agreement with the numpy restatement needs separate multiplies and adds (no fused contraction)
 #pragma clang fp contract(off)
@@ -113,7 +115,80 @@ __global__ void plan_costs_kernel(const bmpc_plan_batch_t d) {
     Xt[6] = am[0]; Xt[7] = am[1]; Xt[8] = am[2];
 }
 
+// whole-body front end: kinematics of x = [q, v] and the quantities the plan builders take
+__global__ void wb_state_kernel(const RobotModelDev *model, const bmpc_wb_plan_batch_t d) {
+    const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= d.B) return;
+    const double *x = d.x + b * kNX;
+    rbd::Pass1 p1;
+    const int fid[kFrameSlots] = {d.foot_frame[0], d.foot_frame[1], d.foot_frame[2], d.foot_frame[3]};
+    rbd::quad_pass1<false>(*model, x, fid, p1);
+    for (int c = 0; c < 3; ++c) {
+        d.com[b * 3 + c] = p1.com[c];
+        d.x_init[b * 9 + c] = p1.com[c];
+        d.x_init[b * 9 + 3 + c] = p1.hg[c] / p1.M;
+        d.x_init[b * 9 + 6 + c] = p1.hg[3 + c];
+    }
+    for (int j = 0; j < 4; ++j) for (int c = 0; c < 3; ++c) d.feet0[(b * 4 + j) * 3 + c] = p1.fx[j][c];
+    const double *vb = d.v_des_body + b * 3;
+    for (int c = 0; c < 3; ++c) d.v_des[b * 3 + c] = p1.Rb[3 * c] * vb[0] + p1.Rb[3 * c + 1] * vb[1] + p1.Rb[3 * c + 2] * vb[2];   // :642-643
+    d.w_des[b] = 0.0;
+    const double yaw = atan2(p1.Rb[3], p1.Rb[0]), cy = cos(yaw), sy = sin(yaw);    // matrixToRpy, roll = pitch = 0 (:173-177)
+    for (int j = 0; j < 4; ++j) {
+        const double ox = d.gait->offsets_xy[j][0], oy = d.gait->offsets_xy[j][1];
+        d.hip_off[(b * 4 + j) * 2] = cy * ox - sy * oy;
+        d.hip_off[(b * 4 + j) * 2 + 1] = sy * ox + cy * oy;
+    }
+    double Rt[9], w[3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rt[3 * i + j] = p1.Rb[3 * j + i];
+    rbd::log3(Rt, w);                                                              // log3(R_des R_q^T), R_des = I (:616-627)
+    for (int c = 0; c < 3; ++c) d.amom[b * 3 + c] = w[c];
+}
+
+// IK task blocks (abstract_cyclic_gen.py:545-562): 4 x {w, frame, ref3} | com {w, ref3} | mom {w, ref6} | state w | ctrl w
+__global__ void wb_tasks_kernel(const bmpc_wb_plan_batch_t d) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nn = d.ik_col + 1;
+    if (id >= (long)d.B * nn) return;
+    const long b = id / nn;
+    const int t = (int)(id % nn);
+    double *tk = d.ik_tasks + id * kNodeTaskDoubles;
+    for (int i = 0; i < kNodeTaskDoubles; ++i) tk[i] = 0.0;
+    if (t < d.ik_col) {
+        for (int j = 0; j < 4; ++j) {
+            const double *c = d.cnt_plan + ((b * d.n_col + t) * 4 + j) * 4;
+            const bool on = c[0] == 1.0, via = !on && d.swing_time[(b * d.n_col + t) * 4 + j] == 1.0;
+            tk[5 * j] = on ? d.swing_wt[0] : (via ? d.swing_wt[1] : 0.0);
+            tk[5 * j + 1] = (double)d.foot_frame[j];
+            tk[5 * j + 2] = c[1]; tk[5 * j + 3] = c[2]; tk[5 * j + 4] = via ? d.step_ht : c[3];
+        }
+    }
+    tk[5 * kFrameSlots] = d.cent_wt[0];
+    tk[5 * kFrameSlots + 4] = d.cent_wt[1];
+    tk[5 * kFrameSlots + 11] = d.reg_wt[0];
+    tk[5 * kFrameSlots + 12] = d.reg_wt[1];
+}
+
 }  // namespace
+
+int launch_wb_plan(const RobotModelDev *model, const bmpc_wb_plan_batch_t &d, hipStream_t st) {
+    hipLaunchKernelGGL(wb_state_kernel, dim3((unsigned)((d.B + 63) / 64)), dim3(64), 0, st, model, d);
+    bmpc_plan_batch_t p;
+    p.B = d.B; p.n_col = d.n_col; p.n_gaits = 1; p.reserved_ = 0;
+    p.gaits = d.gait; p.gait_id = nullptr;
+    p.t0 = d.t0; p.com = d.com; p.feet0 = d.feet0; p.v_des = d.v_des; p.w_des = d.w_des; p.x_init = d.x_init;
+    p.amom = d.amom; p.hip_off = d.hip_off;
+    p.cnt_plan = d.cnt_plan; p.swing_time = d.swing_time; p.dt = d.dt; p.X_nom = d.X_nom; p.X_ter = d.X_ter;
+    const long nf = (long)d.B * 4;
+    hipLaunchKernelGGL(plan_feet_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(plan_costs_kernel, dim3((unsigned)((d.B + 255) / 256)), dim3(256), 0, st, p);
+    const long nt = (long)d.B * (d.ik_col + 1);
+    hipLaunchKernelGGL(wb_tasks_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, d);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(BMPC_DEVICE_ERROR, std::string("whole-body plan kernels: ") + hipGetErrorString(e));
+    return BMPC_OK;
+}
+
 }  // namespace bunmpc
 
 extern "C" int bmpc_plan_batch_device(const bmpc_plan_batch_t *d, void *hip_stream) {

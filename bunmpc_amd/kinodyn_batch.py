@@ -11,12 +11,14 @@ from .inverse_kinematics_cpp import as_device_model
 
 
 class KinoDynDeviceBatch:
-    def __init__(self, wb, model, device="cuda", num_iters=10, maxit=150, ddp_maxiter=100):
+    def __init__(self, wb, model, device="cuda", num_iters=10, maxit=150, ddp_maxiter=100, plan=None):
+        """plan: a plan_batch.DeviceWbPlan whose tensors replace the host-built centroidal inputs and IK task blocks of
+        `wb` (weights and regularisation references still come from wb)"""
         import torch
         self.torch = torch
         self.wb = wb
         self.dm = as_device_model(model)
-        self.dyn = DeviceBatch(wb.dyn, device=device, num_iters=num_iters, maxit=maxit)
+        self.dyn = DeviceBatch(wb.dyn, device=device, num_iters=num_iters, maxit=maxit, plan=plan)
         self.device = self.dyn.device
         B, T = wb.dyn.B, wb.ik_T
         f64 = torch.float64
@@ -24,10 +26,10 @@ class KinoDynDeviceBatch:
         def up(a):
             return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
 
-        self.x = up(wb.x)
-        self.tasks = up(wb.ik_tasks)
+        self.x = up(wb.x) if plan is None else plan.x
+        self.tasks = up(wb.ik_tasks) if plan is None else plan.ik_tasks
         self.state_w, self.ctrl_w, self.x_reg = up(wb.state_w), up(wb.ctrl_w), up(wb.x_reg)
-        self.dt_ik = up(wb.dyn.dt[:, :T])
+        self.dt_ik = up(wb.dyn.dt[:, :T]) if plan is None else plan.dt[:, :T].contiguous()
         lib = _lib.lib()
         self.ws_doubles = lib.bmpc_ik_workspace_doubles(T)
         off = (C.c_long * 8)()

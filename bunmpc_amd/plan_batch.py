@@ -60,3 +60,50 @@ class DevicePlan:
         stream = self.torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(_lib.lib().bmpc_plan_batch_device(C.byref(self.desc), C.c_void_p(stream)))
         return self
+
+
+class DeviceWbPlan:
+    """Whole-body front end on the GPU (bmpc_wb_plan_batch_device): from states x = [q, v], times and body-frame
+    desired velocities to the centroidal batch inputs and the IK task blocks, all left in HBM.  Device counterpart of
+    problems.make_wb_batch (weights / regularisation references stay small host-provided arrays)."""
+
+    def __init__(self, dev_model, gait, offsets_xy, feet, ik, x, t0, v_des_body, H, T, device="cuda"):
+        import torch
+        self.torch, self.device = torch, torch.device(device)
+        f64 = torch.float64
+
+        def up(a):
+            return torch.as_tensor(np.ascontiguousarray(a), dtype=f64, device=self.device).contiguous()
+
+        B = int(np.shape(x)[0])
+        self.B, self.H, self.T = B, H, T
+        raw = (_lib.GaitParams * 1)(gait_struct(gait, offsets_xy))
+        self.gait = torch.frombuffer(bytearray(bytes(raw)), dtype=torch.uint8).to(self.device)
+        self.x, self.t0, self.v_des_body = up(x), up(t0), up(v_des_body)
+
+        def z(*shape):
+            return torch.empty(shape, dtype=f64, device=self.device)
+
+        self.com, self.feet0, self.v_des, self.w_des = z(B, 3), z(B, 4, 3), z(B, 3), z(B)
+        self.hip_off, self.amom, self.x_init = z(B, 4, 2), z(B, 3), z(B, 9)
+        self.cnt_plan, self.swing_time, self.dt = z(B, H, 4, 4), z(B, H, 4), z(B, H)
+        self.X_nom, self.X_ter, self.ik_tasks = z(B, 9 * H), z(B, 9), z(B, T + 1, 33)
+        self.inp = dict(x_init=self.x_init)      # DeviceBatch(plan=...) reads x_init from here
+        d = _lib.WbPlanBatch()
+        d.B, d.n_col, d.ik_col = B, H, T
+        d.model, d.gait = dev_model.h, self.gait.data_ptr()
+        for j in range(4):
+            d.foot_frame[j] = dev_model.model.frame_id(feet[j])
+        d.step_ht = gait.step_ht
+        for k in range(2):
+            d.swing_wt[k], d.cent_wt[k], d.reg_wt[k] = ik["swing_wt"][k], ik["cent_wt"][k], ik["reg_wt"][k]
+        for k in ("x", "t0", "v_des_body", "com", "feet0", "v_des", "w_des", "hip_off", "amom", "x_init", "cnt_plan", "swing_time",
+                  "dt", "X_nom", "X_ter", "ik_tasks"):
+            setattr(d, k, getattr(self, k).data_ptr())
+        self.desc = d
+        self.dev_model = dev_model
+
+    def build(self):
+        stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().bmpc_wb_plan_batch_device(C.byref(self.desc), C.c_void_p(stream)))
+        return self

@@ -271,6 +271,30 @@ typedef struct {
 } bmpc_plan_batch_t;
 int bmpc_plan_batch_device(const bmpc_plan_batch_t *d, void *hip_stream);
 
+/* The same for whole-body states: everything SoloMpcGaitGen.optimize prepares before kd.optimize
+ * (abstract_cyclic_gen.py:629-663 -> create_cnt_plan, create_costs) from x = [q, v], the time and the desired body-frame
+ * velocity, on the device: forward kinematics (CoM, feet, centroidal state), v_des in the world frame, yaw-rotated hip
+ * offsets, the orientation-correction momentum log3(R_q^T), then the contact plan / cost references as above and the
+ * IK task blocks of bmpc_ik_batch_t (frame tasks from the plan; CoM / momentum weights, their references are filled
+ * by bmpc_kinodyn_solve_batch_device).  w_des = 0 (the data path).  Outputs feed bmpc_kinodyn_solve_batch_device. */
+typedef struct {
+    int B, n_col, ik_col, reserved_;
+    const bmpc_model_t *model;
+    const bmpc_gait_params_t *gait;    /* device, one entry; offsets_xy in the body frame */
+    int foot_frame[4];                 /* frame indices of the end effectors (eff_names) */
+    double step_ht, swing_wt[2], cent_wt[2], reg_wt[2];   /* weight_abstract.py fields the task list uses */
+    const double *x;                   /* [B][37] */
+    const double *t0;                  /* [B] */
+    const double *v_des_body;          /* [B][3] */
+    /* intermediates (device, caller-allocated): */
+    double *com, *feet0, *v_des, *w_des, *hip_off, *amom;   /* [B][3], [B][4][3], [B][3], [B], [B][4][2], [B][3] */
+    /* outputs: */
+    double *x_init;                    /* [B][9] centroidal state of x */
+    double *cnt_plan, *swing_time, *dt, *X_nom, *X_ter;
+    double *ik_tasks;                  /* [B][ik_col + 1][33] */
+} bmpc_wb_plan_batch_t;
+int bmpc_wb_plan_batch_device(const bmpc_wb_plan_batch_t *d, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,3 +60,40 @@ def test_solve_from_device_built_inputs(oracle):
     for k in "XFP":
         assert np.array_equal(got[k], ref[k])
     assert np.all(rel_l2(got["X"], oracle.solve_batch(b, num_iters=10)["X"]) < 1e-5)
+
+
+def test_whole_body_plan_on_the_device(oracle):
+    """bmpc_wb_plan_batch_device against problems.make_wb_batch (FK in numpy): same plan, costs, IK task blocks up to
+    the last bits of the kinematics, and the KinoDyn solve from the device-built inputs equals the host-built one"""
+    import os
+    from bunmpc_amd import urdf_model
+    from bunmpc_amd.inverse_kinematics_cpp import as_device_model
+    from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
+    from bunmpc_amd.plan_batch import DeviceWbPlan
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    model = urdf_model.RobotModel.from_json(open(os.path.join(root, "bunmpc_amd", "robots", "solo12.json")).read())
+    B = 40
+    wb = problems.make_wb_batch(model, B)
+    dm = as_device_model(model)
+    # the harness' hip offsets (rounded, widened) in the body frame of the nominal configuration
+    from bunmpc_amd import fk_np
+    k0 = fk_np.kinematics(model, problems.SOLO12_Q0[None])
+    offs = np.round(fk_np.frame_positions(model, k0, problems.HIPS)[0] - k0["com"][0], 3)
+    offs[:, 1] += np.array([0.04, -0.04, 0.04, -0.04])
+    p = DeviceWbPlan(dm, problems.TROT, offs[:, :2], problems.FEET, problems.TROT_IK, wb.x, wb.dyn.meta["t0"], wb.dyn.meta["v_des_body"],
+                     wb.dyn.H, wb.ik_T).build()
+    tol = dict(rtol=0, atol=1e-12)
+    assert np.allclose(p.x_init.cpu().numpy(), wb.dyn.x_init, **tol)
+    assert np.allclose(p.cnt_plan.cpu().numpy(), wb.dyn.cnt_plan, **tol) and np.array_equal(p.swing_time.cpu().numpy(), wb.dyn.swing_time)
+    assert np.array_equal(p.dt.cpu().numpy(), wb.dyn.dt)
+    assert np.allclose(p.X_nom.cpu().numpy(), wb.dyn.X_nom, **tol) and np.allclose(p.X_ter.cpu().numpy(), wb.dyn.X_ter, **tol)
+    assert np.allclose(p.ik_tasks.cpu().numpy(), wb.ik_tasks, **tol)
+    a = KinoDynDeviceBatch(wb, model, num_iters=10, plan=p)
+    a.solve()
+    ra = a.results()
+    b = KinoDynDeviceBatch(wb, model, num_iters=10)
+    b.solve()
+    rb = b.results()
+    assert np.array_equal(ra["ik_iters"], rb["ik_iters"]) and np.all(ra["ik_status"] == 0)
+    assert np.all(rel_l2(ra["X"], rb["X"]) < 1e-9)
+    assert np.all(rel_l2(ra["xs"].reshape(B, -1), rb["xs"].reshape(B, -1)) < 1e-8)
