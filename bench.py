@@ -136,7 +136,26 @@ def kinodyn_leg(dev, B, admm_iters, maxit, config="solo12_h20", steps=3):
     torch.cuda.synchronize(dev)
     dt_ik = (time.perf_counter() - t1) / steps
     r = kb.results()
+    # the inputs of the same batch built on the device from the raw states (bmpc_wb_plan_batch_device)
+    plan_ms = None
+    if config == "solo12_h20":
+        from bunmpc_amd import fk_np
+        from bunmpc_amd.inverse_kinematics_cpp import as_device_model
+        from bunmpc_amd.plan_batch import DeviceWbPlan
+        k0 = fk_np.kinematics(model, problems.SOLO12_Q0[None])
+        offs = np.round(fk_np.frame_positions(model, k0, problems.HIPS)[0] - k0["com"][0], 3)
+        offs[:, 1] += np.array([0.04, -0.04, 0.04, -0.04])
+        p = DeviceWbPlan(as_device_model(model), problems.TROT, offs[:, :2], problems.FEET, problems.TROT_IK, wb.x, wb.dyn.meta["t0"],
+                         wb.dyn.meta["v_des_body"], wb.dyn.H, wb.ik_T, device=dev)
+        p.build()
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        for _ in range(10):
+            p.build()
+        torch.cuda.synchronize(dev)
+        plan_ms = (time.perf_counter() - t2) / 10 * 1e3
     return {"value": B / dt, "unit": "KinoDynMP solves/s", "workload": "%s H=%d H_ik=%d" % (config, wb.dyn.H, wb.ik_T),
+            "device_built_inputs_ms": plan_ms,
             "batch": B, "ms_per_step": dt * 1e3,
             "ik_only_ms_per_step": dt_ik * 1e3, "ddp_iters_mean": float(r["ik_iters"].mean()),
             "ddp_iters_max": int(r["ik_iters"].max()), "ddp_not_converged": int((r["ik_status"] != 0).sum()),
