@@ -144,7 +144,7 @@ constexpr int kResLd = kRes + 1;                // 22 doubles = 11 x 16 bytes pe
 constexpr int kParts = kLegs + 1;        // legs 0..3, base body 4
 constexpr int kPartDoubles = 16;         // Comp (m, h1[3], I[6]) + momentum about the origin (6)
 
-struct alignas(16) CalcLds {
+struct alignas(16) CalcNode {         // per node of the workgroup
     double Jt[kNDX][kResLd];
     double JlT[6][6];                 // Jlog6 block of the state residual Jacobian, transposed: JlT[i][k] = Jl[6 k + i]
     double parts[kParts][kPartDoubles];
@@ -152,24 +152,25 @@ struct alignas(16) CalcLds {
     double fx[kFrameSlots][3];        // task-frame positions (written by the part that carries the frame)
     double rs[kNDX];                  // state residual
     double cost_kin, cost_sc;         // node cost: momentum + CoM + frames | state + control
-    RobotModelDev m;
-    double x[kNX], u[kNV];
+    double x[kNX + 1], u[kNV];
 };
+constexpr int kCalcNodes = 2;
+struct alignas(16) CalcLds { CalcNode nd[kCalcNodes]; RobotModelDev m; };
 
-// Workgroup = two waves per (problem, node).  Wave 0: lanes 0..17 each walk their own part of the robot once (base
-// lanes the base body, joint lanes their leg), the five part sums meet in LDS, every lane finishes its column.  Wave 1,
-// meanwhile: the state residual with its Jlog6 block and the Euler step with its Jintegrate blocks (one lane; a
-// different instruction stream, so it would serialise inside wave 0).  Then both waves assemble the Gauss-Newton
-// L_x / L_xx, lane j = column j, rows split between the waves.
+// Workgroup = two waves for TWO nodes of a problem.  Wave 0: lanes 0..17 (node A) and 32..49 (node B) each walk their
+// own part of the robot once (base lanes the base body, joint lanes their leg), the five part sums of a node meet in
+// LDS, every lane finishes its column.  Wave 1, meanwhile, on lanes 0 and 32: the state residual with its Jlog6 block
+// and the Euler step with its Jintegrate blocks (a different instruction stream, so it would serialise inside wave
+// 0).  Then wave w assembles the Gauss-Newton L_x / L_xx of node w, lane j = column j.  Two nodes share every
+// instruction of the walk: the walk keeps 36 of 64 lanes busy instead of 18.
 __global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a) {
     __shared__ CalcLds s;
-    const int nn = a.T + 1;
-    const long b = blockIdx.x / nn;
-    const int t = blockIdx.x % nn, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nn = a.T + 1, groups = (nn + kCalcNodes - 1) / kCalcNodes;
+    const long b = blockIdx.x / groups;
+    const int t0 = (blockIdx.x % groups) * kCalcNodes, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const IkLayout L = IkLayout::make(a.T);
     double *ws = a.ws + b * L.total;
     if (ws[L.scal + S_DONE] != 0.0 || ws[L.scal + S_RECALC] == 0.0) return;
-    const bool terminal = t == a.T;
 #ifdef BWD_PROFILE
     long long pc[6] = {0, 0, 0, 0, 0, 0}, pt0 = __builtin_readcyclecounter();
 #endif
@@ -179,33 +180,44 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a
         for (int i = threadIdx.x; i < (int)(sizeof(RobotModelDev) / sizeof(int)); i += 128) dst[i] = src[i];
     }
     const RobotModelDev &m = s.m;
-    NodeTasks tk{a.tasks + (b * nn + t) * kNodeTaskDoubles};
     const double *state_w = batch_ptr(a.state_w, a.s_state_w, b), *ctrl_w = batch_ptr(a.ctrl_w, a.s_ctrl_w, b);
-    const double dt = terminal ? 0.0 : a.dt[b * a.T + t];
-    if (threadIdx.x < kNX) s.x[threadIdx.x] = ws[L.xs + (long)t * kNX + threadIdx.x];
-    if (threadIdx.x >= 64 && lane < kNV) s.u[lane] = terminal ? 0.0 : ws[L.us + (long)t * kNV + lane];
+    {   // states and controls of both nodes: wave w stages node w
+        const int t = t0 + wave;
+        if (t < nn) {
+            CalcNode &q = s.nd[wave];
+            if (lane < kNX) q.x[lane] = ws[L.xs + (long)t * kNX + lane];
+            if (lane < kNV) q.u[lane] = t == a.T ? 0.0 : ws[L.us + (long)t * kNV + lane];
+        }
+    }
     __syncthreads();
     PSTAMP(0)
-    const double wm = tk.mom_w(), wc = tk.com_w(), wst = tk.state_w(), wu = tk.ctrl_w();
+    // ---- walk phase: node index = half of the wave
+    const int hs = lane >> 5, hl = lane & 31, tw = t0 + hs;
+    const bool wvalid = tw < nn;
+    CalcNode &qw = s.nd[hs];
+    NodeTasks tkw{a.tasks + (b * nn + (wvalid ? tw : t0)) * kNodeTaskDoubles};
+    const bool terminal_w = tw == a.T;
+    const double dtw = (terminal_w || !wvalid) ? 0.0 : a.dt[b * a.T + tw];
     PartWalk pw;
     double Rb[9], pb[3], Vb[6];
-    if (wave == 0 && lane < kNV) {
+    if (wave == 0 && wvalid && hl < kNV) {
         int fid[kFrameSlots];
-        UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) fid[f] = tk.frame_w(f) != 0.0 ? tk.frame_id(f) : -1;
-        quad_part_walk(m, s.x, fid, lane, Rb, pb, Vb, pw);
-        const bool leg_pub = lane >= 6 && (lane - 6) % kLegJoints == 0;
-        if (lane == 0 || leg_pub) {   // one publisher per part
-            double *pp = s.parts[lane == 0 ? kLegs : (lane - 6) / kLegJoints];
+        UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) fid[f] = tkw.frame_w(f) != 0.0 ? tkw.frame_id(f) : -1;
+        quad_part_walk(m, qw.x, fid, hl, Rb, pb, Vb, pw);
+        const bool leg_pub = hl >= 6 && (hl - 6) % kLegJoints == 0;
+        if (hl == 0 || leg_pub) {   // one publisher per part
+            double *pp = qw.parts[hl == 0 ? kLegs : (hl - 6) / kLegJoints];
             pp[0] = pw.part.m;
             UNROLL_RBD for (int c = 0; c < 3; ++c) pp[1 + c] = pw.part.h1[c];
             UNROLL_RBD for (int c = 0; c < 6; ++c) { pp[4 + c] = pw.part.I[c]; pp[10 + c] = pw.hpart[c]; }
             UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
-                if (pw.fhit[f]) { UNROLL_RBD for (int c = 0; c < 3; ++c) s.fx[f][c] = pw.fx[f][c]; }
+                if (pw.fhit[f]) { UNROLL_RBD for (int c = 0; c < 3; ++c) qw.fx[f][c] = pw.fx[f][c]; }
         }
-    } else if (wave == 1 && lane == 0) {   // state residual + its Jacobian block, Euler step, their part of the node cost
+    } else if (wave == 1 && wvalid && hl == 0) {   // state residual + its Jacobian block, Euler step, their part of the node cost
+        const double wst = tkw.state_w(), wu = tkw.ctrl_w();
         double rs[kNDX], Jl[36], cost = 0.0;
         if (wst != 0.0) {
-            state_diff<true>(a.x_reg + b * kNX, s.x, rs, Jl);
+            state_diff<true>(a.x_reg + b * kNX, qw.x, rs, Jl);
             double acc = 0.0;
             UNROLL_RBD for (int i = 0; i < kNDX; ++i) acc += state_w[i] * rs[i] * rs[i];
             cost += wst * 0.5 * acc;
@@ -213,27 +225,27 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a
             UNROLL_RBD for (int i = 0; i < kNDX; ++i) rs[i] = 0.0;
             UNROLL_RBD for (int i = 0; i < 36; ++i) Jl[i] = (i % 7 == 0) ? 1.0 : 0.0;
         }
-        UNROLL_RBD for (int i = 0; i < kNDX; ++i) s.rs[i] = rs[i];
-        UNROLL_RBD for (int i = 0; i < 6; ++i) UNROLL_RBD for (int k = 0; k < 6; ++k) s.JlT[i][k] = Jl[6 * k + i];
-        if (!terminal) {
+        UNROLL_RBD for (int i = 0; i < kNDX; ++i) qw.rs[i] = rs[i];
+        UNROLL_RBD for (int i = 0; i < 6; ++i) UNROLL_RBD for (int k = 0; k < 6; ++k) qw.JlT[i][k] = Jl[6 * k + i];
+        if (!terminal_w) {
             double acc = 0.0;
-            UNROLL_RBD for (int i = 0; i < kNV; ++i) acc += ctrl_w[i] * s.u[i] * s.u[i];
+            UNROLL_RBD for (int i = 0; i < kNV; ++i) acc += ctrl_w[i] * qw.u[i] * qw.u[i];
             cost += wu * 0.5 * acc;
             double xn[kNX], A6[36], B6[36];
-            euler_step<true>(s.x, s.u, dt, xn, A6, B6);
-            UNROLL_RBD for (int i = 0; i < kNX; ++i) ws[L.xnext + (long)t * kNX + i] = xn[i];
-            UNROLL_RBD for (int i = 0; i < 36; ++i) { ws[L.A6 + (long)t * 36 + i] = A6[i]; ws[L.B6 + (long)t * 36 + i] = B6[i]; }
+            euler_step<true>(qw.x, qw.u, dtw, xn, A6, B6);
+            UNROLL_RBD for (int i = 0; i < kNX; ++i) ws[L.xnext + (long)tw * kNX + i] = xn[i];
+            UNROLL_RBD for (int i = 0; i < 36; ++i) { ws[L.A6 + (long)tw * 36 + i] = A6[i]; ws[L.B6 + (long)tw * 36 + i] = B6[i]; }
         }
-        s.cost_sc = cost;
+        qw.cost_sc = cost;
     }
     __syncthreads();
     PSTAMP(1)
-    if (wave == 0 && lane < kNV) {   // robot totals from the five parts, then this lane's column
+    if (wave == 0 && wvalid && hl < kNV) {   // robot totals from the five parts, then this lane's column
         Comp call; double hO[6];
         {
             double2_t pa[20], pb2[20];
-            lds_read_b128x20(lds_offset(s.parts), pa);
-            lds_read_b128x20(lds_offset(s.parts) + 320, pb2);
+            lds_read_b128x20(lds_offset(qw.parts), pa);
+            lds_read_b128x20(lds_offset(qw.parts) + 320, pb2);
             double tot[kPartDoubles];
             UNROLL_RBD for (int k = 0; k < kPartDoubles; ++k) {
                 double acc = 0.0;
@@ -253,16 +265,16 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a
         UNROLL_RBD for (int c = 0; c < 3; ++c) com[c] = call.h1[c] * iM;
         cross3(com, hO, t3);
         UNROLL_RBD for (int c = 0; c < 3; ++c) { hg[c] = hO[c]; hg[3 + c] = hO[3 + c] - t3[c]; }
-        if (lane < 6) { pw.cs = call; UNROLL_RBD for (int c = 0; c < 6; ++c) pw.hs[c] = hO[c]; }   // base columns move the whole robot
+        if (hl < 6) { pw.cs = call; UNROLL_RBD for (int c = 0; c < 6; ++c) pw.hs[c] = hO[c]; }   // base columns move the whole robot
         Column c;
         quad_col_finish(pw, M, com, hO, c);
-        double *cq = s.Jt[lane], *cv = s.Jt[kNV + lane];
+        double *cq = qw.Jt[hl], *cv = qw.Jt[kNV + hl];
         UNROLL_RBD for (int k = 0; k < 6; ++k) { cq[k] = c.dh[k]; cv[k] = c.ag[k]; }
         UNROLL_RBD for (int k = 0; k < 3; ++k) cq[6 + k] = c.jc[k];
         UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) {
             double j3[3] = {0, 0, 0};
-            if (tk.frame_w(f) != 0.0 && quad_supports(m, tk.frame_id(f), lane)) {
-                const double fxf[3] = {s.fx[f][0], s.fx[f][1], s.fx[f][2]};
+            if (tkw.frame_w(f) != 0.0 && quad_supports(m, tkw.frame_id(f), hl)) {
+                const double fxf[3] = {qw.fx[f][0], qw.fx[f][1], qw.fx[f][2]};
                 cross3(c.S + 3, fxf, j3);
                 UNROLL_RBD for (int k = 0; k < 3; ++k) j3[k] += c.S[k];
             }
@@ -270,41 +282,50 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a
         }
         cq[kRes] = 0.0;
         UNROLL_RBD for (int k = 6; k < kResLd; ++k) cv[k] = 0.0;
-        if (lane == 0) {   // residuals and their cost
+        if (hl == 0) {   // residuals and their cost
             double cost = 0.0, acc = 0.0;
-            UNROLL_RBD for (int k = 0; k < 6; ++k) { const double rr = hg[k] - tk.mom_ref()[k]; s.res[k] = rr; acc += rr * rr; }
-            cost += wm * 0.5 * acc;
+            UNROLL_RBD for (int k = 0; k < 6; ++k) { const double rr = hg[k] - tkw.mom_ref()[k]; qw.res[k] = rr; acc += rr * rr; }
+            cost += tkw.mom_w() * 0.5 * acc;
             acc = 0.0;
-            UNROLL_RBD for (int k = 0; k < 3; ++k) { const double rr = com[k] - tk.com_ref()[k]; s.res[6 + k] = rr; acc += rr * rr; }
-            cost += wc * 0.5 * acc;
+            UNROLL_RBD for (int k = 0; k < 3; ++k) { const double rr = com[k] - tkw.com_ref()[k]; qw.res[6 + k] = rr; acc += rr * rr; }
+            cost += tkw.com_w() * 0.5 * acc;
             UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) {
-                const double w = tk.frame_w(f);
+                const double w = tkw.frame_w(f);
                 acc = 0.0;
-                UNROLL_RBD for (int k = 0; k < 3; ++k) { const double rr = w != 0.0 ? s.fx[f][k] - tk.frame_ref(f)[k] : 0.0; s.res[9 + 3 * f + k] = rr; acc += rr * rr; }
+                UNROLL_RBD for (int k = 0; k < 3; ++k) { const double rr = w != 0.0 ? qw.fx[f][k] - tkw.frame_ref(f)[k] : 0.0; qw.res[9 + 3 * f + k] = rr; acc += rr * rr; }
                 cost += w * 0.5 * acc;
             }
-            s.res[kRes] = 0.0;
-            s.cost_kin = cost;
+            qw.res[kRes] = 0.0;
+            qw.cost_kin = cost;
         }
     }
     __syncthreads();
     PSTAMP(2)
+    // ---- assembly phase: wave w owns node t0 + w
+    const int t = t0 + wave;
+    if (t >= nn) return;
+    CalcNode &q = s.nd[wave];
+    NodeTasks tk{a.tasks + (b * nn + t) * kNodeTaskDoubles};
+    const bool terminal = t == a.T;
+    const double dt = terminal ? 0.0 : a.dt[b * a.T + t];
+    const double wm = tk.mom_w(), wc = tk.com_w(), wst = tk.state_w(), wu = tk.ctrl_w();
     const double sc = terminal ? 1.0 : dt;
-    if (wave == 1 && !terminal && lane < kNV) {
-        ws[L.Lu + (long)t * kNV + lane] = sc * wu * ctrl_w[lane] * s.u[lane];
-        ws[L.Luu + (long)t * kNV + lane] = sc * wu * ctrl_w[lane];
+    if (!terminal && lane >= 40 && lane < 40 + kNV) {     // lanes the assembly leaves idle
+        const int i = lane - 40;
+        ws[L.Lu + (long)t * kNV + i] = sc * wu * ctrl_w[i] * q.u[i];
+        ws[L.Luu + (long)t * kNV + i] = sc * wu * ctrl_w[i];
     }
     // node costs are summed by the backward kernel: parked in the fs slot of this node
-    if (threadIdx.x == 0) ws[L.fs + (long)t * kNDX] = terminal ? s.cost_kin + s.cost_sc : dt * (s.cost_kin + s.cost_sc);
+    if (lane == 63) ws[L.fs + (long)t * kNDX] = terminal ? q.cost_kin + q.cost_sc : dt * (q.cost_kin + q.cost_sc);
     if (lane >= kNDX) return;
     // Gauss-Newton L_x / L_xx, lane j = column j:  L_xx[i][j] = sum_k J[k][i] w_k J[k][j]  (+ the state regularisation
     // block), the weighted own column in registers, row i's column read back by broadcast (ds_read_b128 batches),
-    // stores coalesced across j.  Row pairs alternate between the two waves.
+    // stores coalesced across j.
     const int j = lane;
     double jw[kRes];
     {
         double2_t own[11];
-        lds_read_b128x11(lds_offset(s.Jt[j]), own);
+        lds_read_b128x11(lds_offset(q.Jt[j]), own);
         UNROLL_RBD for (int k = 0; k < kRes; ++k) jw[k] = (k & 1) ? own[k >> 1].y : own[k >> 1].x;
     }
     UNROLL_RBD for (int k = 0; k < 6; ++k) jw[k] *= wm;
@@ -313,19 +334,19 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a
         UNROLL_RBD for (int k = 0; k < 3; ++k) jw[9 + 3 * f + k] *= tk.frame_w(f);
     const double swj = wst * state_w[j];
     double jlw[6];     // wst * state_w[k] * Jl[k][j] for the 6x6 free-flyer block of the state residual Jacobian
-    UNROLL_RBD for (int k = 0; k < 6; ++k) jlw[k] = j < 6 ? wst * state_w[k] * s.JlT[j][k] : 0.0;
-    if (wave == 0) {   // L_x
+    UNROLL_RBD for (int k = 0; k < 6; ++k) jlw[k] = j < 6 ? wst * state_w[k] * q.JlT[j][k] : 0.0;
+    {   // L_x
         double2_t rr[11];
-        lds_read_b128x11(lds_offset(s.res), rr);
+        lds_read_b128x11(lds_offset(q.res), rr);
         double g = 0.0;
         UNROLL_RBD for (int k = 0; k < kRes; ++k) g += jw[k] * ((k & 1) ? rr[k >> 1].y : rr[k >> 1].x);
-        if (j < 6) { UNROLL_RBD for (int k = 0; k < 6; ++k) g += jlw[k] * s.rs[k]; }
-        else g += swj * s.rs[j];
+        if (j < 6) { UNROLL_RBD for (int k = 0; k < 6; ++k) g += jlw[k] * q.rs[k]; }
+        else g += swj * q.rs[j];
         ws[L.Lx + (long)t * kNDX + j] = sc * g;
     }
     double *Lxx = ws + L.Lxx + (long)t * kNDX * kNDX;
-    const unsigned jt_addr = lds_offset(s.Jt), jl_addr = lds_offset(s.JlT);
-    for (int i0 = 2 * wave; i0 < 6; i0 += 4) {    // rows of the free-flyer block: all 21 residual rows + the Jlog6 block
+    const unsigned jt_addr = lds_offset(q.Jt), jl_addr = lds_offset(q.JlT);
+    for (int i0 = 0; i0 < 6; i0 += 2) {    // rows of the free-flyer block: all 21 residual rows + the Jlog6 block
         double2_t ri[22], jl[3], jl2[3];
         lds_read_b128x22(jt_addr + (unsigned)i0 * (kResLd * 8), ri);
         lds_read_b128x3(jl_addr + (unsigned)i0 * 48, jl);
@@ -342,7 +363,7 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a
         Lxx[(long)i0 * kNDX + j] = sc * h0;
         Lxx[(long)(i0 + 1) * kNDX + j] = sc * h1;
     }
-    for (int i0 = 6 + 2 * ((wave + 1) & 1); i0 < kNV; i0 += 4) {   // joint rows
+    for (int i0 = 6; i0 < kNV; i0 += 2) {   // joint rows
         double2_t ri[22];
         lds_read_b128x22(jt_addr + (unsigned)i0 * (kResLd * 8), ri);
         double h0 = 0.0, h1 = 0.0;
@@ -353,7 +374,7 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a
         Lxx[(long)i0 * kNDX + j] = sc * (h0 + (i0 == j ? swj : 0.0));
         Lxx[(long)(i0 + 1) * kNDX + j] = sc * (h1 + (i0 + 1 == j ? swj : 0.0));
     }
-    for (int i0 = kNV + 2 * wave; i0 < kNDX; i0 += 4) {      // velocity rows: only the 6 momentum rows are non-zero
+    for (int i0 = kNV; i0 < kNDX; i0 += 2) {      // velocity rows: only the 6 momentum rows are non-zero
         double2_t ra[3], rb[3];
         lds_read_b128x3(jt_addr + (unsigned)i0 * (kResLd * 8), ra);
         lds_read_b128x3(jt_addr + (unsigned)(i0 + 1) * (kResLd * 8), rb);
@@ -932,7 +953,7 @@ hipError_t ik_launch_init(const IkBatchArgs &a, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t ik_launch_calcdiff(const IkBatchArgs &a, hipStream_t st) {
-    const long n = (long)a.B * (a.T + 1);
+    const long n = (long)a.B * ((a.T + 1 + 1) / 2);   // two nodes per workgroup
     hipLaunchKernelGGL(ik_calcdiff_kernel, dim3((unsigned)n), dim3(128), 0, st, a);
     return hipGetLastError();
 }
