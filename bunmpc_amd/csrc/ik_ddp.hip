@@ -669,9 +669,15 @@ struct ForwardLds { RobotModelDev m; FwdSub sub[kFwdSub]; double vote[kFwdSub], 
 //      first that passes, trials are independent of each other, so running them side by side and taking the first
 //      passing one is the same decision -- it trades idle SIMDs for a 4x shorter serial chain when few problems
 //      are still iterating.
-__global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
+//
+// NW = 2 (used with the speculative mapping): a second wave takes the cost side of every node (state regularisation
+// residual, leg walks, their sum) while wave 0 runs the chain x -> dx -> u -> Euler step -> next x; the two meet once per
+// node.  Different code cannot overlap inside a wave, but it can across the waves of a workgroup.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a) {
     __shared__ ForwardLds s;
-    const int lane = threadIdx.x, si = lane / kFwdLanes, l = lane % kFwdLanes;
+    const int lane = threadIdx.x & 63, wave = NW == 2 ? (int)(threadIdx.x >> 6) : 0, si = lane / kFwdLanes, l = lane % kFwdLanes;
+    const bool do_chain = NW == 1 || wave == 0, do_cost = NW == 1 || wave == 1;
     const bool spec = a.fwd_spec != 0;
     const long b = spec ? (long)blockIdx.x : (long)blockIdx.x * kFwdSub + si;
     const bool pvalid = b < a.B;
@@ -687,9 +693,9 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
     {   // the robot model is read many times per node: stage it in LDS once
         const int *src = reinterpret_cast<const int *>(a.model);
         int *dst = reinterpret_cast<int *>(&s.m);
-        for (int i = lane; i < (int)(sizeof(RobotModelDev) / sizeof(int)); i += 64) dst[i] = src[i];
+        for (int i = threadIdx.x; i < (int)(sizeof(RobotModelDev) / sizeof(int)); i += 64 * NW) dst[i] = src[i];
     }
-    if (live) {
+    if (live && do_chain) {
         const double *gsw = batch_ptr(a.state_w, a.s_state_w, bb), *gcw = batch_ptr(a.ctrl_w, a.s_ctrl_w, bb), *gxr = a.x_reg + bb * kNX;
         for (int i = l; i < kNX; i += kFwdLanes) q.xreg[i] = gxr[i];
         for (int i = l; i < kNDX; i += kFwdLanes) q.sw[i] = gsw[i];
@@ -712,14 +718,14 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
         const double al = ldexp(1.0, -ia);
         if (!spec && live) alpha = al;
         double ctry = 0.0;
-        if (run) {
+        if (run && do_chain) {
             for (int i = l; i < kNX; i += kFwdLanes) { q.x[i] = ws[L.xs_try + i]; q.xs[i] = ws[L.xs + i]; }   // x0 sits in slot 0
             for (int i = l; i < kNodeTaskDoubles; i += kFwdLanes) q.tk[i] = gtasks[i];
             if (l == 0) q.tk[kNodeTaskDoubles] = gdt[0];
         }
         // feedback rows of node 0 (lanes 0..8 own rows l and l + 9): fetched one node ahead of their use from here on
         double kp0[kNDX], kp1[kNDX], up0 = 0.0, up1 = 0.0, fp0 = 0.0, fp1 = 0.0;
-        if (run && l < 9) {
+        if (run && do_chain && l < 9) {
             const double *K0 = ws + L.K + (long)l * kNDX, *K1 = K0 + 9 * kNDX;
             UNROLL_RBD for (int j = 0; j < kNDX; ++j) { kp0[j] = K0[j]; kp1[j] = K1[j]; }
             up0 = ws[L.us + l]; up1 = ws[L.us + l + 9]; fp0 = ws[L.kff + l]; fp1 = ws[L.kff + l + 9];
@@ -732,7 +738,7 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
             const double dtn = terminal ? 0.0 : q.tk[kNodeTaskDoubles];
             // next node's task block / dt / nominal state: requested now, parked in LDS at the end of this node
             double ntk[3] = {0.0, 0.0, 0.0}, nxs[3] = {0.0, 0.0, 0.0};
-            if (run && !terminal) {
+            if (run && do_chain && !terminal) {
                 const double *g = gtasks + (long)(t + 1) * kNodeTaskDoubles;
                 UNROLL_RBD for (int k = 0; k < 3; ++k) {
                     const int i = l + kFwdLanes * k;
@@ -741,9 +747,9 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
                     if (i < kNX) nxs[k] = ws[L.xs + (long)(t + 1) * kNX + i];
                 }
             }
-            // phase 1, lanes 0 and 5 in one instruction stream: dx = xs[t] (-) x (feeds the feedback) and the state
-            // regularisation residual x_reg (-) x (feeds the cost)
-            const bool want_dx = l == 0 && !terminal, want_rs = l == 5 && tk.state_w() != 0.0;
+            // phase 1: dx = xs[t] (-) x on lane 0 (feeds the feedback) and the state regularisation residual x_reg (-) x on
+            // lane 5 (feeds the cost) -- one instruction stream when one wave does both
+            const bool want_dx = do_chain && l == 0 && !terminal, want_rs = do_cost && l == 5 && tk.state_w() != 0.0;
             if (run && (want_dx || want_rs)) {
                 double d[kNDX];
                 state_diff<false>(want_dx ? q.xs : x_reg, q.x, d, nullptr);
@@ -753,9 +759,9 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
                     UNROLL_RBD for (int i = 0; i < kNDX; ++i) acc += state_w[i] * d[i] * d[i];
                     q.bc[2] = tk.state_w() * 0.5 * acc;
                 }
-            } else if (run && l == 5) q.bc[2] = 0.0;
+            } else if (run && do_cost && l == 5) q.bc[2] = 0.0;
             // phase 2 (needs x only): legs on lanes 0..3, base body on lane 4
-            if (run && l <= kLegs) {
+            if (run && do_cost && l <= kLegs) {
                 int fid[kFrameSlots];
                 UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) fid[f] = tk.frame_w(f) != 0.0 ? tk.frame_id(f) : -1;
                 PartSum ps;
@@ -766,9 +772,9 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
                 UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
                     UNROLL_RBD for (int c = 0; c < 3; ++c) q.part[l][10 + 3 * f + c] = ps.fhit[f] ? ps.fx[f][c] : 0.0;
             }
-            __syncthreads();
-            // phase 3: feedback u = u - alpha k - K dx, two rows per lane (0..8 own rows l and l + 9), their 72 reads in flight together
-            if (run && !terminal && l < 9) {
+            if (NW == 1) __syncthreads();   // with two waves each side hands over inside its own wave (LDS keeps a wave's order)
+            // phase 3: feedback u = u - alpha k - K dx, two rows per lane (0..8 own rows l and l + 9), rows fetched a node ahead
+            if (run && do_chain && !terminal && l < 9) {
                 double v0 = up0 - al * fp0, v1 = up1 - al * fp1;
                 UNROLL_RBD for (int j = 0; j < kNDX; ++j) { v0 -= kp0[j] * q.dx[j]; v1 -= kp1[j] * q.dx[j]; }
                 q.u[l] = v0; q.u[l + 9] = v1;
@@ -780,9 +786,9 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
                     fp0 = ws[L.kff + (long)(t + 1) * kNV + l]; fp1 = ws[L.kff + (long)(t + 1) * kNV + l + 9];
                 }
             }
-            __syncthreads();
+            if (NW == 1) __syncthreads();
             // phase 4: control cost + Euler step (lane 6)
-            if (run && l == 6) {
+            if (run && do_chain && l == 6) {
                 double acc = 0.0;
                 if (!terminal) {
                     UNROLL_RBD for (int i = 0; i < kNV; ++i) acc += ctrl_w[i] * q.u[i] * q.u[i];
@@ -794,8 +800,9 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
                 } else q.bc[1] = 0.0;
                 q.bc[3] = tk.ctrl_w() * 0.5 * acc;
             }
-            __syncthreads();
-            if (run && l == 0) {   // add the parts: CoM, centroidal momentum, residual costs
+            if (NW == 1) __syncthreads();
+            // phase 5: the parts added up: CoM, centroidal momentum, their residual costs (without the state / control terms)
+            if (run && do_cost && l == 0) {
                 double M = 0.0, h1[3] = {0, 0, 0}, hO[6] = {0, 0, 0, 0, 0, 0}, fx[kFrameSlots][3];
                 UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) fx[f][0] = fx[f][1] = fx[f][2] = 0.0;
                 UNROLL_RBD for (int pa = 0; pa <= kLegs; ++pa) {
@@ -822,14 +829,15 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
                     UNROLL_RBD for (int k = 0; k < 3; ++k) { const double r = w != 0.0 ? fx[f][k] - tk.frame_ref(f)[k] : 0.0; acc += r * r; }
                     c += w * 0.5 * acc;
                 }
-                c += q.bc[2] + q.bc[3];
-                if (!terminal) c *= dtn;
-                if (!(fabs(c) < INFINITY)) q.bc[1] = 1.0;
                 q.bc[0] = c;
             }
             __syncthreads();
             if (run) {
-                if (!terminal) {
+                double c = q.bc[0] + (q.bc[2] + q.bc[3]);     // node cost: residual terms + (state + control)
+                if (!terminal) c *= dtn;
+                const bool bad = q.bc[1] != 0.0 || !(fabs(c) < INFINITY);
+                ctry += c;
+                if (!terminal && do_chain) {
                     for (int i = l; i < kNX; i += kFwdLanes) q.x[i] = q.xn[i];
                     UNROLL_RBD for (int k = 0; k < 3; ++k) {
                         const int i = l + kFwdLanes * k;
@@ -837,8 +845,7 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
                         if (i < kNX) q.xs[i] = nxs[k];
                     }
                 }
-                ctry += q.bc[0];
-                if (q.bc[1] != 0.0) run = false;       // tryStep threw: this step length is out
+                if (bad) run = false;       // tryStep threw: this step length is out
             }
             __syncthreads();
         }
@@ -862,7 +869,7 @@ __global__ __launch_bounds__(64) void ik_forward_kernel(const IkBatchArgs a) {
             __syncthreads();
         }
     }
-    if (!owner) return;
+    if (!owner || !do_chain) return;
     double xreg = sc[S_XREG];
     if (accepted) {   // setCandidate(xs_try, us_try, true)
         const long xsrc = L.xs_try + (long)win * nn * kNX, usrc = L.us_try + (long)win * T * kNV;
@@ -962,7 +969,8 @@ hipError_t ik_launch_backward(const IkBatchArgs &a, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t ik_launch_forward(const IkBatchArgs &a, hipStream_t st) {
-    hipLaunchKernelGGL(ik_forward_kernel, dim3(a.fwd_spec ? a.B : (a.B + 3) / 4), dim3(64), 0, st, a);
+    if (a.fwd_spec) hipLaunchKernelGGL(ik_forward_kernel<2>, dim3(a.B), dim3(128), 0, st, a);
+    else hipLaunchKernelGGL(ik_forward_kernel<1>, dim3((a.B + 3) / 4), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 hipError_t ik_launch_centroidal_state(const RobotModelDev *model, const double *x, double *out9, int B, hipStream_t st) {
