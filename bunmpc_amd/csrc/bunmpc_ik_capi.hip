@@ -168,12 +168,20 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run) {
     a.fwd_spec = 0;
     if (int rc = g_active_word.ensure()) return rc;
     HIP_TRY(bunmpc::ik_launch_init(a, st));
+    // The host looks at the active counter after every iteration while many problems are iterating (iterations are long
+    // there and the line-search mapping depends on it); once few are left it enqueues kTailChunk iterations per look --
+    // kernels of a finished problem return at once, so an iteration too many costs a few microseconds, while every
+    // look costs a drained queue.
+    constexpr int kTailChunk = 3;
     int active = a.B, it = 0;
-    for (; it < a.maxiter && active > 0; ++it) {
-        HIP_TRY(bunmpc::ik_launch_calcdiff(a, st));
-        HIP_TRY(bunmpc::ik_launch_backward(a, st));
+    while (it < a.maxiter && active > 0) {
+        const int chunk = active <= g_spec_line_search_below ? kTailChunk : 1;
         a.fwd_spec = active <= g_spec_line_search_below ? 1 : 0;
-        HIP_TRY(bunmpc::ik_launch_forward(a, st));
+        for (int k = 0; k < chunk && it < a.maxiter; ++k, ++it) {
+            HIP_TRY(bunmpc::ik_launch_calcdiff(a, st));
+            HIP_TRY(bunmpc::ik_launch_backward(a, st));
+            HIP_TRY(bunmpc::ik_launch_forward(a, st));
+        }
         HIP_TRY(bunmpc::ik_launch_publish_active(a.active, g_active_word.dev, st));
         HIP_TRY(hipStreamSynchronize(st));
         active = *static_cast<volatile int *>(g_active_word.host);
