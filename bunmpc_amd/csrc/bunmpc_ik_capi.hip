@@ -150,6 +150,7 @@ bunmpc::IkBatchArgs make_args(int B, int T, int maxiter, const bmpc_model *model
 // below this many active problems the forward pass runs four step lengths of a problem side by side (one wave per
 // problem: 1024 SIMDs on an MI355X)
 int g_spec_line_search_below = 1024;
+constexpr int kMaxIkCol = 63;     // T + 1 <= 64 nodes: the backward pass computes the gaps one lane per node
 
 // one host-mapped word per host thread, through which the kernels' active counter reaches the DDP loop
 struct ActiveWord {
@@ -271,6 +272,7 @@ double bmpc_model_total_mass(const bmpc_model_t *m) { return m ? m->host.total_m
 // ----------------------------------------------------------- InverseKinematics ----
 bmpc_ik_t *bmpc_ik_create(const bmpc_model_t *model, int n_col) {
     if (!model || n_col < 1) { ik_fail(BMPC_BAD_ARG, "bad InverseKinematics arguments"); return nullptr; }
+    if (n_col > kMaxIkCol) { ik_fail(BMPC_BAD_ARG, "n_col > 63 is not supported (one lane per node in the gap computation)"); return nullptr; }
     auto *h = new bmpc_ik;
     h->model = model; h->n_col = n_col;
     h->dt.assign(n_col, 0.0);
@@ -466,6 +468,7 @@ int bmpc_ik_solve_batch_device(const bmpc_ik_batch_t *d, void *hip_stream) {
     using namespace bunmpc;
     if (!d || !d->model) return ik_fail(BMPC_BAD_ARG, "null batch descriptor / model");
     if (d->B < 0 || d->n_col < 1 || d->maxiter < 1) return ik_fail(BMPC_BAD_ARG, "bad sizes");
+    if (d->n_col > kMaxIkCol) return ik_fail(BMPC_BAD_ARG, "n_col > 63 is not supported");
     if (!d->x0 || !d->dt || !d->tasks || !d->state_w || !d->x_reg || !d->ctrl_w || !d->ws || !d->active)
         return ik_fail(BMPC_BAD_ARG, "missing array");
     if (d->B == 0) return BMPC_OK;

@@ -221,3 +221,34 @@ def test_line_search_scheduling_does_not_change_results(model):
     assert np.array_equal(out[0]["ik_iters"], out[1]["ik_iters"]) and np.all(out[0]["ik_status"] == 0)
     assert np.array_equal(out[0]["xs"], out[1]["xs"]) and np.array_equal(out[0]["us"], out[1]["us"])
     assert np.array_equal(out[0]["ik_cost"], out[1]["ik_cost"])
+
+
+def test_ik_longest_horizon(model):
+    """n_col = 63 (the largest the kernels take: T + 1 = 64 nodes): regularisation + one foot target per node, the
+    numpy DDP on the same problem as the reference"""
+    from bunmpc_amd.inverse_kinematics_cpp import InverseKinematics
+    from oracle import ik_ddp_np
+    T = 63
+    x0 = np.concatenate([Q0, np.zeros(18)])
+    target = np.array([0.21, 0.15, 0.03])
+
+    def costs(ik):
+        for i in range(0, T, 4):
+            ik.add_position_tracking_task_single("FL_FOOT", target, 1e3, "t%d" % i, i)
+        ik.add_state_regularization_cost(0, T, 5e-2, "xReg", STATE_WT, x0, False)
+        ik.add_ctrl_regularization_cost(0, T, 1e-5, "uReg", CTRL_WT, np.zeros(18), False)
+        ik.add_state_regularization_cost(0, T, 5e-2, "xReg", STATE_WT, x0, True)
+        ik.setup_costs(np.full(T, 0.02))
+
+    ik = InverseKinematics(model, T)
+    costs(ik)
+    ik.optimize(x0)
+    st = ik.last_stats()
+    ref_prob = ik_ddp_np.IKProblem(model, T)
+    costs(ref_prob)
+    ref = ik_ddp_np.solve_ddp(ref_prob, x0)
+    assert st["status"] == 0 and st["iters"] == ref["iters"], (st, ref["iters"])
+    assert abs(st["cost"] - ref["cost"]) <= 1e-9 * abs(ref["cost"])
+    assert rel_l2(np.array(ik.get_xs()).reshape(-1), np.array(ref["xs"]).reshape(-1)) < 1e-8
+    with pytest.raises(Exception):
+        InverseKinematics(model, 64)
