@@ -419,6 +419,8 @@ __device__ __forceinline__ double rcp64(double b) {
 struct alignas(16) BackwardLds {
     double N[kNDX * LD];       // row-major staging: N = F_x^T V for the transposition, later Q_xx -> V_xx rows
     double Kt[kNDX * kNV];     // K^T: column j of K contiguous at Kt[18 j], read back by broadcast
+    double Lr[5 * 36], Lc[5 * 36];   // Cholesky factor packed by rows (L[p][q], q < p, at p(p-1)/2 + q) and by columns
+                                     // (L[q][p], q > p, at p(35-p)/2 + q-p-1), read back by broadcast in batches of 36
     double A6[36], B6[36];
     double Vx[kNDX], fs[kNDX];
 };
@@ -560,20 +562,47 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
                 al[j] *= idg[j];                        // L[p][j] for the rows p > j
             }
             PSTAMPV(4, idg[17])
+            // The factor goes to LDS once (u-lanes own its rows): the 37 triangular solves then read it back by broadcast
+            // -- one ds_read_b128 per two entries instead of four v_readlane.
+            if (ul) {
+                const int p = uq;
+                UNROLL_RBD for (int q = 0; q < kNV - 1; ++q) {
+                    if (q < p) { s.Lr[p * (p - 1) / 2 + q] = al[q]; s.Lc[q * (35 - q) / 2 + (p - q - 1)] = al[q]; }
+                }
+            }
+            __syncthreads();
             // K = Quu^-1 Qxu^T: lane j < 36 solves for column j (18 unknowns in registers); lane 36: k = Quu^-1 Qu
             double y[kNV], quv[kNV];
             UNROLL_RBD for (int p = 0; p < kNV; ++p) quv[p] = lane_value(qu, kNV + p);
-            UNROLL_RBD for (int p = 0; p < kNV; ++p) {
-                double w = lane < kNDX ? qxu[p] : quv[p];
-                UNROLL_RBD for (int q = 0; q < p; ++q) w -= lane_value(al[q], kNV + p) * y[q];
-                y[p] = w * idg[p];
+            {
+                const unsigned lr_addr = lds_offset(s.Lr);
+                double2_t lb[18];
+                int cur = -1;
+                UNROLL_RBD for (int p = 0; p < kNV; ++p) {
+                    double w = lane < kNDX ? qxu[p] : quv[p];
+                    UNROLL_RBD for (int q = 0; q < p; ++q) {
+                        const int idx = p * (p - 1) / 2 + q, bb = idx / 36, e = idx % 36;
+                        if (bb != cur) { lds_read_b128x18(lr_addr + (unsigned)bb * 288, lb); cur = bb; }
+                        w -= ((e & 1) ? lb[e >> 1].y : lb[e >> 1].x) * y[q];
+                    }
+                    y[p] = w * idg[p];
+                }
             }
             // expectedImprovement / stoppingCriteria ingredients (lane 36): d2 = -k.Quu k = -|L^T k|^2 = -|L^-1 Qu|^2
             UNROLL_RBD for (int p = 0; p < kNV; ++p) d2 -= y[p] * y[p];
-            UNROLL_RBD for (int p = kNV - 1; p >= 0; --p) {
-                double w = y[p];
-                UNROLL_RBD for (int q = p + 1; q < kNV; ++q) w -= lane_value(al[p], kNV + q) * y[q];
-                y[p] = w * idg[p];
+            {
+                const unsigned lc_addr = lds_offset(s.Lc);
+                double2_t lb[18];
+                int cur = -1;
+                UNROLL_RBD for (int p = kNV - 1; p >= 0; --p) {
+                    double w = y[p];
+                    UNROLL_RBD for (int q = kNV - 1; q > p; --q) {      // descending, so the batches are met from the last to the first
+                        const int idx = p * (35 - p) / 2 + (q - p - 1), bb = idx / 36, e = idx % 36;
+                        if (bb != cur) { lds_read_b128x18(lc_addr + (unsigned)bb * 288, lb); cur = bb; }
+                        w -= ((e & 1) ? lb[e >> 1].y : lb[e >> 1].x) * y[q];
+                    }
+                    y[p] = w * idg[p];
+                }
             }
             PSTAMPV(5, y[0])
             UNROLL_RBD for (int p = 0; p < kNV; ++p) { d1 += quv[p] * y[p]; st += quv[p] * quv[p]; }   // d1 = Qu.k, stop = |Qu|^2
