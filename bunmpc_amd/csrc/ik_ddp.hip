@@ -625,10 +625,10 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             {
                 const unsigned kaddr = lds_offset(Ks);
                 for (int j0 = 0; j0 < kNDX; j0 += 4) {      // four columns per trip: their 36 K^T reads in two back-to-back batches
-                    double2_t ka[18], kb[18];
-                    lds_read_b128x18(kaddr + (unsigned)j0 * (kNV * 8), ka);
+                    double2_t ka[18], kb[18], wr[2];
+                    lds_read_b128x18_and4(kaddr + (unsigned)j0 * (kNV * 8), row_addr + (unsigned)j0 * 8, ka, wr);   // + own row entries
                     lds_read_b128x18(kaddr + (unsigned)(j0 + 2) * (kNV * 8), kb);
-                    double w0 = s.N[r * LD + j0], w1 = s.N[r * LD + j0 + 1], w2 = s.N[r * LD + j0 + 2], w3 = s.N[r * LD + j0 + 3];
+                    double w0 = wr[0].x, w1 = wr[0].y, w2 = wr[1].x, w3 = wr[1].y;
                     UNROLL_RBD for (int p = 0; p < 9; ++p) {
                         w0 -= qxu[2 * p] * ka[p].x; w1 -= qxu[2 * p] * ka[9 + p].x; w2 -= qxu[2 * p] * kb[p].x; w3 -= qxu[2 * p] * kb[9 + p].x;
                         w0 -= qxu[2 * p + 1] * ka[p].y; w1 -= qxu[2 * p + 1] * ka[9 + p].y; w2 -= qxu[2 * p + 1] * kb[p].y; w3 -= qxu[2 * p + 1] * kb[9 + p].y;

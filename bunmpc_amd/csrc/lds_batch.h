@@ -52,6 +52,12 @@ __device__ __forceinline__ void lds_read_b128x20(unsigned addr, double2_t (&o)[2
                  : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15]), "=&v"(o[16]), "=&v"(o[17]), "=&v"(o[18]), "=&v"(o[19])
                  : "v"(addr) : "memory");
 }
+// 18 x 16 bytes from a 16-byte aligned address plus four consecutive doubles from an 8-byte aligned one, one wait
+__device__ __forceinline__ void lds_read_b128x18_and4(unsigned kaddr, unsigned waddr, double2_t (&k)[18], double2_t (&w)[2]) {
+    asm volatile("ds_read_b128 %0, %20 offset:0\n\tds_read_b128 %1, %20 offset:16\n\tds_read_b128 %2, %20 offset:32\n\tds_read_b128 %3, %20 offset:48\n\tds_read_b128 %4, %20 offset:64\n\tds_read_b128 %5, %20 offset:80\n\tds_read_b128 %6, %20 offset:96\n\tds_read_b128 %7, %20 offset:112\n\tds_read_b128 %8, %20 offset:128\n\tds_read_b128 %9, %20 offset:144\n\tds_read_b128 %10, %20 offset:160\n\tds_read_b128 %11, %20 offset:176\n\tds_read_b128 %12, %20 offset:192\n\tds_read_b128 %13, %20 offset:208\n\tds_read_b128 %14, %20 offset:224\n\tds_read_b128 %15, %20 offset:240\n\tds_read_b128 %16, %20 offset:256\n\tds_read_b128 %17, %20 offset:272\n\tds_read2_b64 %18, %21 offset0:0 offset1:1\n\tds_read2_b64 %19, %21 offset0:2 offset1:3\n\t" "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(k[0]), "=&v"(k[1]), "=&v"(k[2]), "=&v"(k[3]), "=&v"(k[4]), "=&v"(k[5]), "=&v"(k[6]), "=&v"(k[7]), "=&v"(k[8]), "=&v"(k[9]), "=&v"(k[10]), "=&v"(k[11]), "=&v"(k[12]), "=&v"(k[13]), "=&v"(k[14]), "=&v"(k[15]), "=&v"(k[16]), "=&v"(k[17]), "=&v"(w[0]), "=&v"(w[1])
+                 : "v"(kaddr), "v"(waddr) : "memory");
+}
 // 36 consecutive doubles (8-byte aligned) with the 18 ds_read2_b64 in flight together
 __device__ __forceinline__ void lds_read_row36(unsigned addr, double (&x)[36]) {
     double2_t t[18];
