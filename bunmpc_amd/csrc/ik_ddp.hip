@@ -14,10 +14,11 @@
 //                       assemble the Gauss-Newton L_x / L_xx by column (coalesced 10 KB store).
 //   ik_backward_kernel  one WAVE per problem, matrix rows in registers (lane r = row r of V, G, Q_xx), exploiting
 //                       F_x = [[A, dt B],[0, I]], F_u = dt F_x[:, v] (A, B identity except a 6x6 free-flyer block):
-//                       G = F_x^T V F_x via one LDS transposition, Cholesky and the gain solves in registers
-//                       over v_readlane, V_xx = Q_xx - Q_xu K against broadcast LDS reads; regularisation
-//                       retries inside the kernel (details above the kernel).
-//   ik_forward_kernel   FOUR problems per wave (16 lanes each): line search 2^-k, k = 0..9 -- feedback
+//                       G = F_x^T V F_x via one LDS transposition, Cholesky in registers over v_readlane, the gain
+//                       solves and V_xx = Q_xx - Q_xu K against broadcast LDS reads; regularisation retries
+//                       inside the kernel (details above the kernel).
+//   ik_forward_kernel   FOUR problems per wave (16 lanes each), or four step lengths of one problem with a second wave for
+//                       the cost side when few problems are left: line search 2^-k, k = 0..9 -- feedback
 //                       u = u - a k - K dx, node evaluation spread over the sub-group's lanes (legs, base, state
 //                       cost, control cost + Euler step); acceptance, regularisation update and stopping test
 //                       as crocoddyl 1.9.0 solver-ddp.cpp.
