@@ -53,6 +53,13 @@ class WbPlanBatch(C.Structure):
                                            "cnt_plan", "swing_time", "dt", "X_nom", "X_ter", "ik_tasks")])
 
 
+class InterpBatch(C.Structure):
+    """bmpc_interp_batch_t"""
+    _fields_ = [("B", C.c_int), ("n_knots", C.c_int), ("width", C.c_int), ("size", C.c_int), ("max_rows", C.c_int),
+                ("dt_stride", C.c_int), ("step", C.c_double), ("knots", C.c_void_p), ("dt", C.c_void_p), ("out", C.c_void_p),
+                ("rows", C.c_void_p)]
+
+
 _lib = None
 
 _D = C.c_double
@@ -117,6 +124,7 @@ _SIGS = {
     "bmpc_biconvex_kernel_name": (C.c_char_p, [_I, _I]),
     "bmpc_plan_batch_device": (_I, [_P, _P]),
     "bmpc_wb_plan_batch_device": (_I, [_P, _P]),
+    "bmpc_interp_batch_device": (_I, [_P, _P]),
     "bmpc_ik_set_speculative_below": (_I, [_I]),
     "bmpc_model_create": (_P, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "bmpc_model_destroy": (None, [_P]),

@@ -169,6 +169,40 @@ __global__ void wb_tasks_kernel(const bmpc_wb_plan_batch_t d) {
     tk[5 * kFrameSlots + 12] = d.reg_wt[1];
 }
 
+// 1 kHz resampling of the first `size` knot intervals of a planned trajectory (abstract_cyclic_gen.py:677-692):
+// vstack_i linspace(knots[i], knots[i+1], int(dt_i / step)) -- end points included and therefore repeated at the
+// seams, as there.  One thread per (problem, output row, component); rows beyond a problem's total are left alone.
+__global__ void interp_kernel(const bmpc_interp_batch_t d) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per = (long)d.max_rows * d.width;
+    if (id >= (long)d.B * per) return;
+    const long b = id / per;
+    const int row = (int)((id % per) / d.width), c = (int)(id % d.width);
+    const double *dt = d.dt + b * d.dt_stride;
+    int i = 0, first = 0, n = 0;
+    for (; i < d.size; ++i) {                      // which interval holds this row
+        n = (int)(dt[i] / d.step);                 // int(dt_arr[i] / 0.001)
+        if (row < first + n) break;
+        first += n;
+    }
+    if (c == 0 && row == 0) {
+        int tot = 0;
+        for (int k = 0; k < d.size; ++k) tot += (int)(dt[k] / d.step);
+        d.rows[b] = tot;
+    }
+    if (i == d.size) return;
+    const int k = row - first;
+    const double a0 = d.knots[(b * d.n_knots + i) * d.width + c], a1 = d.knots[(b * d.n_knots + i + 1) * d.width + c];
+    double y;
+    if (n == 1) y = a0;
+    else if (k == n - 1) y = a1;                   // numpy.linspace sets the end point exactly
+    else {
+        const double stepv = (a1 - a0) / (double)(n - 1);
+        y = stepv == 0.0 ? ((double)k / (double)(n - 1)) * (a1 - a0) + a0 : (double)k * stepv + a0;
+    }
+    d.out[(b * d.max_rows + row) * d.width + c] = y;
+}
+
 }  // namespace
 
 int launch_wb_plan(const RobotModelDev *model, const bmpc_wb_plan_batch_t &d, hipStream_t st) {
@@ -190,6 +224,19 @@ int launch_wb_plan(const RobotModelDev *model, const bmpc_wb_plan_batch_t &d, hi
 }
 
 }  // namespace bunmpc
+
+extern "C" int bmpc_interp_batch_device(const bmpc_interp_batch_t *d, void *hip_stream) {
+    using namespace bunmpc;
+    if (!d || !d->knots || !d->dt || !d->out || !d->rows) return set_error(BMPC_BAD_ARG, "null interpolation argument");
+    if (d->B < 0 || d->size < 1 || d->size >= d->n_knots || d->width < 1 || d->max_rows < 1 || !(d->step > 0.0))
+        return set_error(BMPC_BAD_ARG, "bad interpolation sizes");
+    if (d->B == 0) return BMPC_OK;
+    const long n = (long)d->B * d->max_rows * d->width;
+    hipLaunchKernelGGL(interp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(hip_stream), *d);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(BMPC_DEVICE_ERROR, std::string("interpolation kernel: ") + hipGetErrorString(e));
+    return BMPC_OK;
+}
 
 extern "C" int bmpc_plan_batch_device(const bmpc_plan_batch_t *d, void *hip_stream) {
     using namespace bunmpc;

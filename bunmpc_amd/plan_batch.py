@@ -107,3 +107,20 @@ class DeviceWbPlan:
         stream = self.torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(_lib.lib().bmpc_wb_plan_batch_device(C.byref(self.desc), C.c_void_p(stream)))
         return self
+
+
+def interpolate_on_device(knots, dt, size, step=0.001):
+    """1 kHz plan of a batch of knot trajectories (torch tensors on the GPU): knots (B, n, w), dt (B, H) ->
+    (out (B, max_rows, w), rows (B,)); out[b, :rows[b]] equals cyclic_gen.interpolate_plan(knots[b], dt[b], size)."""
+    import torch
+    B, n, w = knots.shape
+    knots, dt = knots.contiguous(), dt.contiguous()
+    max_rows = int(size * (int(float(dt.max()) / step) + 1))
+    out = torch.zeros((B, max_rows, w), dtype=torch.float64, device=knots.device)
+    rows = torch.zeros(B, dtype=torch.int32, device=knots.device)
+    d = _lib.InterpBatch()
+    d.B, d.n_knots, d.width, d.size, d.max_rows, d.dt_stride, d.step = B, n, w, size, max_rows, dt.shape[1], step
+    d.knots, d.dt, d.out, d.rows = knots.data_ptr(), dt.data_ptr(), out.data_ptr(), rows.data_ptr()
+    stream = torch.cuda.current_stream(knots.device).cuda_stream
+    _lib.check(_lib.lib().bmpc_interp_batch_device(C.byref(d), C.c_void_p(stream)))
+    return out, rows

@@ -295,6 +295,19 @@ typedef struct {
 } bmpc_wb_plan_batch_t;
 int bmpc_wb_plan_batch_device(const bmpc_wb_plan_batch_t *d, void *hip_stream);
 
+/* The 1 kHz plan of SoloMpcGaitGen.optimize (abstract_cyclic_gen.py:677-692) for a batch, on the device:
+ * out[b] = vstack_{i < size} linspace(knots[b][i], knots[b][i+1], int(dt[b][i] / step)), end points included (and so
+ * repeated at the seams, as there).  knots [B][n_knots][width], dt [B][dt_stride] (first `size` entries used),
+ * out [B][max_rows][width], rows [B] = number of rows written for each problem (<= max_rows; more are dropped). */
+typedef struct {
+    int B, n_knots, width, size, max_rows, dt_stride;
+    double step;
+    const double *knots, *dt;
+    double *out;
+    int *rows;
+} bmpc_interp_batch_t;
+int bmpc_interp_batch_device(const bmpc_interp_batch_t *d, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

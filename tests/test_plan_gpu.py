@@ -97,3 +97,24 @@ def test_whole_body_plan_on_the_device(oracle):
     assert np.array_equal(ra["ik_iters"], rb["ik_iters"]) and np.all(ra["ik_status"] == 0)
     assert np.all(rel_l2(ra["X"], rb["X"]) < 1e-9)
     assert np.all(rel_l2(ra["xs"].reshape(B, -1), rb["xs"].reshape(B, -1)) < 1e-8)
+
+
+def test_device_interpolation_is_numpy_linspace():
+    """bmpc_interp_batch_device against cyclic_gen.interpolate_plan (stacked numpy.linspace), bit for bit, with the
+    first interval shortened by the first-knot dt rule for some problems"""
+    import torch
+    from bunmpc_amd.cyclic_gen import interpolate_plan
+    from bunmpc_amd.plan_batch import interpolate_on_device
+    rng = np.random.default_rng(3)
+    B, n, w, size = 17, 11, 37, 3
+    knots = rng.normal(size=(B, n, w))
+    knots[:, 2] = knots[:, 1]                       # a flat interval (linspace step 0)
+    dt = np.full((B, 10), 0.05)
+    dt[::3, 0] = 0.03
+    dt[1::5, 0] = 0.01
+    out, rows = interpolate_on_device(torch.from_numpy(knots).cuda(), torch.from_numpy(dt).cuda(), size)
+    out, rows = out.cpu().numpy(), rows.cpu().numpy()
+    for b in range(B):
+        ref = interpolate_plan(knots[b], dt[b], size)
+        assert rows[b] == ref.shape[0]
+        assert np.array_equal(out[b, :rows[b]], ref), b
