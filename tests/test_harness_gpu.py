@@ -73,3 +73,25 @@ def test_turning_uses_the_composite_inertia():
     # stance feet of a trot at t=0 (FL, HR; phase offsets 0) carry the weight
     F0 = gg.mp.return_opt_f().reshape(-1, 4, 3)[0]
     assert F0[:, 2].sum() > 0.5 * model.total_mass * 9.81
+
+
+def test_batched_mpc_equals_the_harness_call_by_call():
+    """BatchedMpc.optimize (states -> 1 kHz plans, all on the device) against SoloMpcGaitGen.optimize per robot"""
+    from bunmpc_amd.cyclic_gen import SoloMpcGaitGen
+    from bunmpc_amd.mpc_batch import BatchedMpc
+    model = urdf_model.RobotModel.from_json(open(ROBOT).read())
+    B = 5
+    wb = problems.make_wb_batch(model, B)
+    t0, vb = wb.dyn.meta["t0"], wb.dyn.meta["v_des_body"]
+    out = BatchedMpc(model, dyn_iters=10).optimize(wb.x, t0, vb)
+    x_reg = np.concatenate([problems.SOLO12_Q0, np.zeros(18)])
+    gg = SoloMpcGaitGen(model, model, x_reg, 0.05, problems.SOLO12_Q0)
+    rows = out["rows"].cpu().numpy()
+    for i in range(B):
+        gg.update_gait_params(trot_params(), t0[i])
+        q, v = wb.x[i, :19].copy(), wb.x[i, 19:].copy()
+        xs_int, us_int, f_int = gg.optimize(q, v, t0[i], vb[i], 0.0, dyn_iters=10)
+        assert rows[i] == xs_int.shape[0]
+        for name, ref in (("xs_int", xs_int), ("us_int", us_int), ("f_int", f_int)):
+            got = out[name][i, :rows[i]].cpu().numpy()
+            assert rel_l2(got.reshape(-1), ref.reshape(-1)) < 1e-7, (i, name)
