@@ -173,7 +173,8 @@ class IkBatch(C.Structure):
     _fields_ = ([("B", C.c_int), ("n_col", C.c_int), ("maxiter", C.c_int), ("model", C.c_void_p)] +
                 [(n, C.c_void_p) for n in ("x0", "dt", "tasks", "state_w", "x_reg", "ctrl_w")] +
                 [("s_state_w", C.c_long), ("s_ctrl_w", C.c_long), ("ws", C.c_void_p), ("active", C.c_void_p),
-                 ("iters_run", C.c_void_p)])
+                 ("iters_run", C.c_void_p), ("s_x_reg", C.c_long), ("sn_state_w", C.c_long), ("sn_x_reg", C.c_long),
+                 ("sn_ctrl_w", C.c_long)])
 
 
 class KinoDynBatch(C.Structure):

@@ -64,8 +64,6 @@ struct bmpc_ik {
     int n_col;
     std::vector<double> dt;
     std::vector<std::map<std::string, IkItem>> nodes;   // n_col + 1 (last = terminal)
-    std::vector<double> state_w, x_reg, ctrl_w;
-    bool have_state = false, have_ctrl = false;
     // results of the last optimize
     std::vector<double> xs, us;
     int iters = 0, status = 0;
@@ -143,6 +141,7 @@ bunmpc::IkBatchArgs make_args(int B, int T, int maxiter, const bmpc_model *model
     a.B = B; a.T = T; a.maxiter = maxiter; a.model = model->dptr();
     a.x0 = x0; a.dt = dt; a.tasks = tasks; a.state_w = state_w; a.x_reg = x_reg; a.ctrl_w = ctrl_w;
     a.s_state_w = s_sw; a.s_ctrl_w = s_cw; a.ws = ws; a.active = active;
+    a.s_x_reg = bunmpc::kNX; a.sn_state_w = a.sn_x_reg = a.sn_ctrl_w = 0; a.fwd_spec = 0;
     return a;
 }
 
@@ -344,48 +343,39 @@ int bmpc_ik_add_centroidal_momentum_tracking_task(bmpc_ik_t *h, int sn, int en, 
     IK_CHECK(traj);
     return add_traj(h, 2, 6, sn, en, traj, rows, wt, name, is_terminal);   // com_tasks.cpp:30-50
 }
-static int set_state_vecs(bmpc_ik *h, const double *w, const double *xr) {
-    std::vector<double> nw(w, w + bunmpc::kNDX), nx(xr, xr + bunmpc::kNX);
-    if (h->have_state && (nw != h->state_w || nx != h->x_reg))
-        return ik_fail(BMPC_BAD_ARG, "differing stateWeights / x_reg between nodes are not supported");
-    h->state_w = nw; h->x_reg = nx; h->have_state = true;
-    return BMPC_OK;
+// regularisation items carry their own vectors (ref = [stateWeights 36 | x_reg 37] or [controlWeights 18]): the acyclic
+// generator gives every node its own (abstract_acyclic_gen.py:225-290)
+static IkItem state_item(double wt, const double *w, const double *xr) {
+    IkItem it{3, wt, -1, std::vector<double>(w, w + bunmpc::kNDX)};
+    it.ref.insert(it.ref.end(), xr, xr + bunmpc::kNX);
+    return it;
 }
-static int set_ctrl_vec(bmpc_ik *h, const double *w) {
-    std::vector<double> nw(w, w + bunmpc::kNV);
-    if (h->have_ctrl && nw != h->ctrl_w) return ik_fail(BMPC_BAD_ARG, "differing controlWeights between nodes are not supported");
-    h->ctrl_w = nw; h->have_ctrl = true;
-    return BMPC_OK;
-}
+static IkItem ctrl_item(double wt, const double *w) { return IkItem{4, wt, -1, std::vector<double>(w, w + bunmpc::kNV)}; }
 int bmpc_ik_add_state_regularization_cost(bmpc_ik_t *h, int sn, int en, double wt, const char *name, const double *w36, const double *xreg37, int is_terminal) {
     IK_CHECK(w36, xreg37);   // regularization_costs.cpp:8-36
-    if (int rc = set_state_vecs(h, w36, xreg37)) return rc;
-    if (is_terminal) return add_item(h, h->n_col, name, IkItem{3, wt, -1, {}});
+    if (is_terminal) return add_item(h, h->n_col, name, state_item(wt, w36, xreg37));
     if (sn < 0 || en > h->n_col) return ik_fail(BMPC_BAD_ARG, "node range out of bounds");
-    for (int i = sn; i < en; ++i) if (int rc = add_item(h, i, name, IkItem{3, wt, -1, {}})) return rc;
+    for (int i = sn; i < en; ++i) if (int rc = add_item(h, i, name, state_item(wt, w36, xreg37))) return rc;
     return BMPC_OK;
 }
 int bmpc_ik_add_state_regularization_cost_single(bmpc_ik_t *h, int time_step, double wt, const char *name, const double *w36, const double *xreg37) {
     IK_CHECK(w36, xreg37);
     if (time_step < 0 || time_step >= h->n_col) return ik_fail(BMPC_BAD_ARG, "time step out of range");
-    if (int rc = set_state_vecs(h, w36, xreg37)) return rc;
-    return add_item(h, time_step, name, IkItem{3, wt, -1, {}});
+    return add_item(h, time_step, name, state_item(wt, w36, xreg37));
 }
 int bmpc_ik_add_ctrl_regularization_cost(bmpc_ik_t *h, int sn, int en, double wt, const char *name, const double *w18, const double *ureg18, int is_terminal) {
     IK_CHECK(w18);   // regularization_costs.cpp:66-93; u_reg is ignored there (ResidualModelControl(state_))
     (void)ureg18;
-    if (int rc = set_ctrl_vec(h, w18)) return rc;
-    if (is_terminal) return add_item(h, h->n_col, name, IkItem{4, wt, -1, {}});
+    if (is_terminal) return add_item(h, h->n_col, name, ctrl_item(wt, w18));
     if (sn < 0 || en > h->n_col) return ik_fail(BMPC_BAD_ARG, "node range out of bounds");
-    for (int i = sn; i < en; ++i) if (int rc = add_item(h, i, name, IkItem{4, wt, -1, {}})) return rc;
+    for (int i = sn; i < en; ++i) if (int rc = add_item(h, i, name, ctrl_item(wt, w18))) return rc;
     return BMPC_OK;
 }
 int bmpc_ik_add_ctrl_regularization_cost_single(bmpc_ik_t *h, int time_step, double wt, const char *name, const double *w18, const double *ureg18) {
     IK_CHECK(w18);
     (void)ureg18;
     if (time_step < 0 || time_step >= h->n_col) return ik_fail(BMPC_BAD_ARG, "time step out of range");
-    if (int rc = set_ctrl_vec(h, w18)) return rc;
-    return add_item(h, time_step, name, IkItem{4, wt, -1, {}});
+    return add_item(h, time_step, name, ctrl_item(wt, w18));
 }
 
 int bmpc_ik_workspace_doubles(int n_col) { return (int)bunmpc::IkLayout::make(n_col).total; }
@@ -395,20 +385,28 @@ int bmpc_ik_optimize(bmpc_ik_t *h, const double *x0) {
     using namespace bunmpc;
     IK_CHECK(x0);
     auto *model = const_cast<bmpc_model *>(h->model);
-    if (int rc = model->upload()) return rc;
     const int T = h->n_col, nn = T + 1;
     std::vector<double> tasks;
-    if (int rc = pack_tasks(h, tasks)) return rc;
+    if (int rc = pack_tasks(h, tasks)) return rc;     // host-side validation first: its errors need no GPU
+    if (int rc = model->upload()) return rc;
     const IkLayout L = IkLayout::make(T);
-    std::vector<double> sw = h->have_state ? h->state_w : std::vector<double>(kNDX, 0.0);
-    std::vector<double> xr = h->have_state ? h->x_reg : std::vector<double>(kNX, 0.0);
-    if (!h->have_state) xr[6] = 1.0;
-    std::vector<double> cw = h->have_ctrl ? h->ctrl_w : std::vector<double>(kNV, 0.0);
+    // per-node regularisation vectors (nodes without the cost keep a neutral reference; their weight is 0 anyway)
+    std::vector<double> sw((size_t)nn * kNDX, 0.0), xr((size_t)nn * kNX, 0.0), cw((size_t)nn * kNV, 0.0);
+    for (int t = 0; t < nn; ++t) {
+        xr[(size_t)t * kNX + 6] = 1.0;
+        for (const auto &kv : h->nodes[t]) {
+            const IkItem &it = kv.second;
+            if (it.kind == 3) {
+                std::copy(it.ref.begin(), it.ref.begin() + kNDX, sw.begin() + (size_t)t * kNDX);
+                std::copy(it.ref.begin() + kNDX, it.ref.end(), xr.begin() + (size_t)t * kNX);
+            } else if (it.kind == 4) std::copy(it.ref.begin(), it.ref.end(), cw.begin() + (size_t)t * kNV);
+        }
+    }
     // staging: x0 | dt | tasks | state_w | x_reg | ctrl_w
     std::vector<double> stage;
     auto push = [&](const double *p, size_t n) { size_t o = stage.size(); stage.insert(stage.end(), p, p + n); return o; };
     const size_t o_x0 = push(x0, kNX), o_dt = push(h->dt.data(), T), o_tk = push(tasks.data(), tasks.size()),
-                 o_sw = push(sw.data(), kNDX), o_xr = push(xr.data(), kNX), o_cw = push(cw.data(), kNV);
+                 o_sw = push(sw.data(), sw.size()), o_xr = push(xr.data(), xr.size()), o_cw = push(cw.data(), cw.size());
     HIP_TRY(h->din.ensure(sizeof(double) * stage.size()));
     HIP_TRY(h->dws.ensure(sizeof(double) * (size_t)L.total));
     HIP_TRY(h->dactive.ensure(sizeof(int)));
@@ -416,6 +414,7 @@ int bmpc_ik_optimize(bmpc_ik_t *h, const double *x0) {
     const double *d = h->din.d();
     IkBatchArgs a = make_args(1, T, 100, model, d + o_x0, d + o_dt, d + o_tk, d + o_sw, 0, d + o_xr, d + o_cw, 0, h->dws.d(),
                               static_cast<int *>(h->dactive.p));
+    a.sn_state_w = kNDX; a.sn_x_reg = kNX; a.sn_ctrl_w = kNV;
     if (int rc = run_ddp(a, nullptr, nullptr)) return rc;
     h->xs.resize((size_t)nn * kNX); h->us.resize((size_t)T * kNV);
     double scal[16];
@@ -425,7 +424,6 @@ int bmpc_ik_optimize(bmpc_ik_t *h, const double *x0) {
     h->iters = (int)scal[S_ITERS]; h->status = (int)scal[S_STATUS]; h->cost = scal[S_COST]; h->stop = scal[S_STOP];
     h->solved = true;
     for (auto &m : h->nodes) m.clear();   // rcost_arr_[i] / tcost_model_ replaced by empty CostModelSums
-    h->have_state = h->have_ctrl = false;
     return BMPC_OK;
 }
 int bmpc_ik_get_xs(const bmpc_ik_t *h, double *xs) {
@@ -476,6 +474,8 @@ int bmpc_ik_solve_batch_device(const bmpc_ik_batch_t *d, void *hip_stream) {
     if (int rc = model->upload()) return rc;
     IkBatchArgs a = make_args(d->B, d->n_col, d->maxiter, model, d->x0, d->dt, d->tasks, d->state_w, d->s_state_w, d->x_reg,
                               d->ctrl_w, d->s_ctrl_w, d->ws, d->active);
+    a.s_x_reg = d->s_x_reg ? d->s_x_reg : kNX;
+    a.sn_state_w = d->sn_state_w; a.sn_x_reg = d->sn_x_reg; a.sn_ctrl_w = d->sn_ctrl_w;
     int iters = 0;
     int rc = run_ddp(a, static_cast<hipStream_t>(hip_stream), &iters);
     if (d->iters_run) *d->iters_run = iters;

@@ -181,7 +181,8 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a
         for (int i = threadIdx.x; i < (int)(sizeof(RobotModelDev) / sizeof(int)); i += 128) dst[i] = src[i];
     }
     const RobotModelDev &m = s.m;
-    const double *state_w = batch_ptr(a.state_w, a.s_state_w, b), *ctrl_w = batch_ptr(a.ctrl_w, a.s_ctrl_w, b);
+    const double *state_w0 = batch_ptr(a.state_w, a.s_state_w, b), *ctrl_w0 = batch_ptr(a.ctrl_w, a.s_ctrl_w, b);
+    const double *x_reg0 = a.x_reg + b * a.s_x_reg;
     {   // states and controls of both nodes: wave w stages node w
         const int t = t0 + wave;
         if (t < nn) {
@@ -216,9 +217,10 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a
         }
     } else if (wave == 1 && wvalid && hl == 0) {   // state residual + its Jacobian block, Euler step, their part of the node cost
         const double wst = tkw.state_w(), wu = tkw.ctrl_w();
+        const double *state_w = state_w0 + a.sn_state_w * tw, *ctrl_w = ctrl_w0 + a.sn_ctrl_w * tw;
         double rs[kNDX], Jl[36], cost = 0.0;
         if (wst != 0.0) {
-            state_diff<true>(a.x_reg + b * kNX, qw.x, rs, Jl);
+            state_diff<true>(x_reg0 + a.sn_x_reg * tw, qw.x, rs, Jl);
             double acc = 0.0;
             UNROLL_RBD for (int i = 0; i < kNDX; ++i) acc += state_w[i] * rs[i] * rs[i];
             cost += wst * 0.5 * acc;
@@ -310,6 +312,7 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a
     const bool terminal = t == a.T;
     const double dt = terminal ? 0.0 : a.dt[b * a.T + t];
     const double wm = tk.mom_w(), wc = tk.com_w(), wst = tk.state_w(), wu = tk.ctrl_w();
+    const double *state_w = state_w0 + a.sn_state_w * t, *ctrl_w = ctrl_w0 + a.sn_ctrl_w * t;
     const double sc = terminal ? 1.0 : dt;
     if (!terminal && lane >= 40 && lane < 40 + kNV) {     // lanes the assembly leaves idle
         const int i = lane - 40;
@@ -725,12 +728,14 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
         int *dst = reinterpret_cast<int *>(&s.m);
         for (int i = threadIdx.x; i < (int)(sizeof(RobotModelDev) / sizeof(int)); i += 64 * NW) dst[i] = src[i];
     }
-    if (live && do_chain) {
-        const double *gsw = batch_ptr(a.state_w, a.s_state_w, bb), *gcw = batch_ptr(a.ctrl_w, a.s_ctrl_w, bb), *gxr = a.x_reg + bb * kNX;
-        for (int i = l; i < kNX; i += kFwdLanes) q.xreg[i] = gxr[i];
-        for (int i = l; i < kNDX; i += kFwdLanes) q.sw[i] = gsw[i];
-        for (int i = l; i < kNV; i += kFwdLanes) q.cw[i] = gcw[i];
-    }
+    const double *gsw = batch_ptr(a.state_w, a.s_state_w, bb), *gcw = batch_ptr(a.ctrl_w, a.s_ctrl_w, bb), *gxr = a.x_reg + bb * a.s_x_reg;
+    const bool per_node = (a.sn_state_w | a.sn_x_reg | a.sn_ctrl_w) != 0;    // time-varying regularisation (acyclic plans)
+    auto stage_reg = [&](int t) {     // regularisation reference and weights of node t into LDS
+        for (int i = l; i < kNX; i += kFwdLanes) q.xreg[i] = gxr[a.sn_x_reg * t + i];
+        for (int i = l; i < kNDX; i += kFwdLanes) q.sw[i] = gsw[a.sn_state_w * t + i];
+        if (t < a.T || a.sn_ctrl_w == 0) { for (int i = l; i < kNV; i += kFwdLanes) q.cw[i] = gcw[a.sn_ctrl_w * t + i]; }
+    };
+    if (live && do_chain) stage_reg(0);
     __syncthreads();
     const RobotModelDev &m = s.m;
     const double cost = sc[S_COST], d1 = sc[S_D1], d2 = sc[S_D2];
@@ -749,6 +754,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
         if (!spec && live) alpha = al;
         double ctry = 0.0;
         if (run && do_chain) {
+            if (per_node && round > 0) stage_reg(0);
             for (int i = l; i < kNX; i += kFwdLanes) { q.x[i] = ws[L.xs_try + i]; q.xs[i] = ws[L.xs + i]; }   // x0 sits in slot 0
             for (int i = l; i < kNodeTaskDoubles; i += kFwdLanes) q.tk[i] = gtasks[i];
             if (l == 0) q.tk[kNodeTaskDoubles] = gdt[0];
@@ -868,6 +874,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
                 const bool bad = q.bc[1] != 0.0 || !(fabs(c) < INFINITY);
                 ctry += c;
                 if (!terminal && do_chain) {
+                    if (per_node) stage_reg(t + 1);
                     for (int i = l; i < kNX; i += kFwdLanes) q.x[i] = q.xn[i];
                     UNROLL_RBD for (int k = 0; k < 3; ++k) {
                         const int i = l + kFwdLanes * k;

@@ -77,6 +77,8 @@ struct IkBatchArgs {
     const double *x_reg;       // [B][37]
     const double *ctrl_w;      // [B or 1][18]
     long s_state_w, s_ctrl_w;  // batch strides (0 = shared)
+    long s_x_reg;              // batch stride of x_reg (37 for [B][37])
+    long sn_state_w, sn_x_reg, sn_ctrl_w;   // node strides (0 = the same vector at every node of a problem)
     double *ws;                // [B][layout.total]
     int *active;               // device counter of problems still iterating
 };

@@ -196,7 +196,9 @@ int bmpc_ik_last_stats(const bmpc_ik_t *h, int *iters, int *status, double *cost
 /* batch of independent IK problems (additive).  Device pointers:
  *   x0 [B][37], dt [B][n_col], tasks [B][n_col+1][BMPC_IK_NODE_TASK_DOUBLES] per node:
  *       4 x {weight, frame, ref(3)} | com {weight, ref(3)} | mom {weight, ref(6)} | state weight | ctrl weight
- *   state_w [.][36], ctrl_w [.][18] (batch stride 0 = shared), x_reg [B][37]
+ *   state_w [.][36], ctrl_w [.][18] (batch stride 0 = shared), x_reg [B][37]; with node strides sn_* != 0 these are per
+ *       node too: state_w [.][n_col+1][36], x_reg [.][n_col+1][37] (batch stride s_x_reg, 0 = 37), ctrl_w [.][n_col][18]
+ *       (what the acyclic generator's time-varying add_*_regularization_cost_single calls produce)
  *   ws [B][bmpc_ik_workspace_doubles(n_col)] scratch + results (offsets: bmpc_ik_layout), active: one int */
 #define BMPC_IK_NODE_TASK_DOUBLES 33
 typedef struct {
@@ -207,6 +209,7 @@ typedef struct {
     double *ws;
     int *active;
     int *iters_run;   /* host int or NULL: DDP iterations the loop executed */
+    long s_x_reg, sn_state_w, sn_x_reg, sn_ctrl_w;   /* 0 = defaults: x_reg [B][37], one vector per problem */
 } bmpc_ik_batch_t;
 int bmpc_ik_workspace_doubles(int n_col);
 void bmpc_ik_layout(int n_col, long *offsets8);

@@ -95,3 +95,85 @@ def test_batched_mpc_equals_the_harness_call_by_call():
         for name, ref in (("xs_int", xs_int), ("us_int", us_int), ("f_int", f_int)):
             got = out[name][i, :rows[i]].cpu().numpy()
             assert rel_l2(got.reshape(-1), ref.reshape(-1)) < 1e-7, (i, name)
+
+
+def crouch_plan(model):
+    """An ACyclicMotionParams-shaped plan (weight_abstract.py:44-80): stand, then crouch -- two phases of nominal height,
+    regularisation posture and weights, so the per-node regularisation vectors differ along the horizon."""
+    q_stand = problems.SOLO12_Q0.copy()
+    q_crouch = q_stand.copy()
+    q_crouch[2] -= 0.05
+    q_crouch[7:] = np.array([0, 1.0, -2.0] * 2 + [0, -1.0, 2.0] * 2)
+    feet = np.array([[0.1946, 0.14695, 0.018], [0.1946, -0.14695, 0.018], [-0.1946, 0.14695, 0.018], [-0.1946, -0.14695, 0.018]])
+    p = types.SimpleNamespace()
+    p.n_col, p.dt_arr, p.plan_freq = 12, np.full(12, 0.05), [[0.3, 0, 2.0]]
+    p.cnt_plan = [[[1.0, *feet[j], 0.0, 2.0] for j in range(4)]]
+    p.W_X = np.array([1e-5, 1e-5, 1e5, 1e1, 1e1, 2e2, 1e4, 1e4, 1e4])
+    p.W_X_ter = 10 * p.W_X
+    p.W_F = np.array(4 * [1e1, 1e1, 1e1])
+    p.rho = 5e4
+    p.X_nom = [[0, 0, 0.22, 0, 0, 0, 0, 0, 0, 0.0, 0.3], [0, 0, 0.17, 0, 0, 0, 0, 0, 0, 0.3, 2.0]]
+    p.X_ter = np.array([0, 0, 0.17, 0, 0, 0, 0, 0, 0.0])
+    p.bounds = [[-0.25, -0.25, 0.1, 0.25, 0.25, 0.3, 0.0, 2.0]]
+    p.cnt_wt, p.swing_wt, p.cent_wt = 1e3, None, [1e-1, 5e1]
+    sw1 = np.array([0., 0, 10] + [1000] * 3 + [1.0] * 12 + [0.] * 3 + [100] * 3 + [0.5] * 12)
+    sw2 = np.array([0., 0, 100] + [500] * 3 + [10.0] * 12 + [0.] * 3 + [100] * 3 + [1.0] * 12)
+    p.state_reg = [np.hstack([q_stand, np.zeros(18), 0.0, 0.3]), np.hstack([q_crouch, np.zeros(18), 0.3, 2.0])]
+    p.state_wt = [np.hstack([sw1, 0.0, 0.3]), np.hstack([sw2, 0.3, 2.0])]
+    p.state_scale = [[1e-2, 0.0, 0.3], [5e-2, 0.3, 2.0]]
+    cw = np.array([1e-2, 0, 1000] + [5e2] * 3 + [1.0] * 12)
+    p.ctrl_wt = [np.hstack([cw, 0.0, 0.3]), np.hstack([2 * cw, 0.3, 2.0])]
+    p.ctrl_reg = [np.hstack([np.zeros(18), 0.0, 0.3]), np.hstack([np.zeros(18), 0.3, 2.0])]
+    p.ctrl_scale = [[1e-4, 0.0, 0.3], [1e-4, 0.3, 2.0]]
+    p.kp, p.kd = [[2.5, 0.0, 2.0]], [[0.08, 0.0, 2.0]]
+    return p, q_stand
+
+
+def test_acyclic_generator_with_time_varying_regularisation():
+    """SoloAcyclicGen (abstract_acyclic_gen.py) on a stand -> crouch plan: the per-node regularisation vectors reach the
+    kernels, and the IK solution equals the numpy DDP given the same task list and the GPU's centroidal solution"""
+    from bunmpc_amd.acyclic_gen import SoloAcyclicGen
+    from oracle import ik_ddp_np
+    model = urdf_model.RobotModel.from_json(open(ROBOT).read())
+    plan, q0 = crouch_plan(model)
+    v0 = np.zeros(18)
+    gen = SoloAcyclicGen(model, model)
+    gen.dyn_iters = 10
+    gen.update_motion_params(plan, q0, 0.0)
+    xs_int, us_int, f_int = gen.optimize(q0.copy(), v0, 0.1)
+    T = plan.n_col
+    assert xs_int.shape == (T * 50, 37) and us_int.shape == (T * 50, 18) and f_int.shape == (T * 50, 12)
+    xs = np.array(gen.ik.get_xs())
+    assert np.array_equal(xs_int[0], xs[0]) and np.array_equal(xs_int[49], xs[0]) and np.array_equal(xs_int[50], xs[1])   # zero-order hold
+    assert gen.get_plan_freq(0.5) == 0.3 and gen.get_gains(0.5) == (2.5, 0.08)
+
+    class FakeKd:   # same cost calls, recorded by the numpy problem instead of the GPU handle
+        def __init__(self):
+            self.ikp = ik_ddp_np.IKProblem(model, T)
+            self.dyn = types.SimpleNamespace(**{k: (lambda *a, **kw: None) for k in
+                                                ("set_rho", "set_contact_plan", "create_bound_constraints", "create_cost_X", "create_cost_F")})
+        def set_com_tracking_weight(self, w): pass
+        def set_mom_tracking_weight(self, w): pass
+        def return_ik(self): return self.ikp
+        def return_dyn(self): return self.dyn
+
+    ref_gen = SoloAcyclicGen(model, model)
+    fake = FakeKd()
+    ref_gen._make_kd = lambda: fake
+    ref_gen.ee_frame_id = list(ref_gen.eff_names)          # the numpy problem addresses frames by name
+    ref_gen.update_motion_params(plan, q0, 0.0)
+    ref_gen.create_contact_plan(q0.copy(), v0, 0.1)
+    ref_gen.create_costs(q0.copy(), v0, 0.1)
+    assert np.array_equal(ref_gen.cnt_plan, gen.cnt_plan) and np.array_equal(ref_gen.X_nom, gen.X_nom)
+    X = gen.mp.return_opt_x().reshape(-1, 9)
+    mom = np.hstack([model.total_mass * X[:, 3:6], X[:, 6:9]])
+    prob = fake.ikp                                           # tracking tasks as KinoDynMP::optimize adds them (kino_dyn.cpp:50-56)
+    prob.add_centroidal_momentum_tracking_task(0, T, mom[:T], plan.cent_wt[1], "mom_track", False)
+    prob.add_centroidal_momentum_tracking_task(0, T, mom[T:T + 1], plan.cent_wt[1], "mom_track_ter", True)
+    prob.add_com_position_tracking_task(0, T, X[:T, 0:3], plan.cent_wt[0], "com_track", False)
+    prob.add_com_position_tracking_task(0, T, X[T:T + 1, 0:3], plan.cent_wt[0], "com_track", True)
+    r = ik_ddp_np.solve_ddp(prob, np.concatenate([q0, v0]))
+    assert gen.ik.last_stats()["iters"] == r["iters"] and r["converged"]
+    assert rel_l2(xs.reshape(-1), np.array(r["xs"]).reshape(-1)) < 1e-8
+    # the regularisation really differs along the horizon: the late nodes sit near the crouch posture
+    assert abs(xs[-1][8] - 1.0) < abs(xs[-1][8] - 0.8)

@@ -103,8 +103,11 @@ def test_ik_host_side_argument_checking(model):
     with pytest.raises(ValueError):
         ik.add_state_regularization_cost(0, 3, 1.0, "xReg", np.ones(5), np.zeros(37), False)
     ik.add_state_regularization_cost(0, 3, 1.0, "xReg", np.ones(36), np.zeros(37), False)
-    with pytest.raises(_lib.BmpcError):                                          # differing weights between nodes
-        ik.add_state_regularization_cost_single(1, 1.0, "other", 2 * np.ones(36), np.zeros(37))
+    ik.add_state_regularization_cost_single(1, 1.0, "xReg", 2 * np.ones(36), np.zeros(37))   # duplicate name: dropped (warning)
+    ik.add_state_regularization_cost_single(1, 1.0, "other", 2 * np.ones(36), np.zeros(37))  # a second state cost on node 1 ...
+    with pytest.raises(_lib.BmpcError) as e:                                                 # ... is refused when the problem is packed
+        ik.optimize(np.concatenate([Q0, np.zeros(18)]))
+    assert e.value.code == 1
     ik.add_velocity_tracking_task(0, 0, 3, np.zeros(3), 1.0, "v")               # prints "function not implemented"
     with pytest.raises(_lib.BmpcError):
         ik.get_xs()                                                              # optimize not called yet
