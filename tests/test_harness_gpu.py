@@ -175,5 +175,13 @@ def test_acyclic_generator_with_time_varying_regularisation():
     r = ik_ddp_np.solve_ddp(prob, np.concatenate([q0, v0]))
     assert gen.ik.last_stats()["iters"] == r["iters"] and r["converged"]
     assert rel_l2(xs.reshape(-1), np.array(r["xs"]).reshape(-1)) < 1e-8
+    # the other line-search mapping (four problems per wave, one wave) reads the per-node vectors the same way
+    from bunmpc_amd import _lib
+    old = _lib.lib().bmpc_ik_set_speculative_below(0)
+    try:
+        gen.optimize(q0.copy(), v0, 0.1)
+    finally:
+        _lib.lib().bmpc_ik_set_speculative_below(old)
+    assert np.array_equal(np.array(gen.ik.get_xs()), xs)
     # the regularisation really differs along the horizon: the late nodes sit near the crouch posture
     assert abs(xs[-1][8] - 1.0) < abs(xs[-1][8] - 0.8)
