@@ -335,9 +335,7 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
                     invL = R(1) / L_f;
                 }
                 const bool last = act && (done || i == maxit - 1);
-                if (__any(last)) {   // x_k of a finishing problem goes straight to its output block
-                    if (last && rvalid) { UNROLL for (int j = 0; j < NF; ++j) Fg[j] = xn[j]; }
-                }
+                if (last && rvalid) { UNROLL for (int j = 0; j < NF; ++j) Fg[j] = xn[j]; }   // x_k of a finishing problem is latched
                 // momentum (fista.cpp:33-47); A-images follow by linearity
                 UNROLL for (int j = 0; j < NF; ++j) y[j] = fmaR(cm, xn[j] - xo[j], xn[j]);
                 UNROLL for (int k = 0; k < 6; ++k) ry[k] = fmaR(cm, rn[k] - ro[k], rn[k]);
@@ -493,9 +491,7 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
                     invL = R(1) / L_x;
                 }
                 const bool last = act && (done || i == maxit - 1);
-                if (__any(last)) {
-                    if (last && kvalid) { UNROLL for (int l = 0; l < 9; ++l) Xg[l] = xn[l]; }
-                }
+                if (last && kvalid) { UNROLL for (int l = 0; l < 9; ++l) Xg[l] = xn[l]; }
                 UNROLL for (int l = 0; l < 9; ++l) {
                     y[l] = fmaR(cm, xn[l] - xo[l], xn[l]);
                     ry[l] = fmaR(cm, rn[l] - ro[l], rn[l]);
