@@ -171,7 +171,7 @@ def main():
     ap.add_argument("--config", default="solo12_trot")
     ap.add_argument("--admm-iters", type=int, default=10)
     ap.add_argument("--maxit", type=int, default=150)
-    ap.add_argument("--cpu-sample", type=int, default=256)
+    ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-kinodyn", action="store_true")
@@ -272,6 +272,8 @@ def main():
             out["p50_latency_ms_batch1"] = p50_latency(args.config, args.admm_iters)
         if world == 1 and not args.no_kinodyn:
             out["kinodyn_full_solve"] = kinodyn_leg(dev, args.kinodyn_batch, args.admm_iters, args.maxit, args.kinodyn_config)
+            if args.kinodyn_config == "solo12_h20":   # BASELINE config 5's shape as well (1024 problems = its per-GPU share)
+                out["kinodyn_go2_h60"] = kinodyn_leg(dev, 1024, args.admm_iters, args.maxit, "go2_h60")
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
