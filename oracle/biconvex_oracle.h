@@ -84,6 +84,16 @@ int orc_biconvex_solve_batch(int B, int n_col, int n_eff, double m, const orc_pa
                              double *L_x, double *L_f, int num_iters,
                              int *stats, int nthreads);
 
+/* Same arguments and results, matrix-free (biconvex_fast.c): the faster CPU baseline of bench.py. */
+int orc_fast_solve_batch(int B, int n_col, int n_eff, double m, const orc_params_t *prm,
+                         const double *cnt_plan, const double *dt, const double *x_init,
+                         const double *Qx, const double *qx,
+                         const double *Qf, const double *qf,
+                         const double *lbx, const double *ubx, int shared_cost,
+                         double *X, double *F, double *P,
+                         double *L_x, double *L_f, int num_iters,
+                         int *stats, int nthreads);
+
 /* biconvex.cpp:27-55 -- X box from the contact plan; b is [n_col][6]. */
 void orc_create_bound_constraints(int n_col, int n_eff, const double *cnt_plan,
                                   const double *b, double *lbx, double *ubx);

@@ -111,8 +111,9 @@ def biconvex_solve(cnt_plan, dt, m, x_init, Qx, qx, Qf, lbx, ubx, X, F, P, L_x=2
 
 
 def solve_batch(batch, num_iters=10, maxit=150, tol=1e-5, exit_tol=1e-3, nthreads=0,
-                L_x=2.25e6, L_f=506.25, warm=None):
-    """Solve a bunmpc_amd.problems.Batch with the C oracle (cold start unless warm=(X,F,P))."""
+                L_x=2.25e6, L_f=506.25, warm=None, fast=False):
+    """Solve a bunmpc_amd.problems.Batch with the C oracle (cold start unless warm=(X,F,P)).
+    fast=True: the matrix-free variant (biconvex_fast.c) instead of the strict restatement."""
     B, H, E = batch.B, batch.H, batch.E
     nx, nf = 9 * (H + 1), 3 * E * H
     Qx = np.empty((B, nx)); qx = np.empty((B, nx)); lbx = np.empty((B, nx)); ubx = np.empty((B, nx))
@@ -128,7 +129,8 @@ def solve_batch(batch, num_iters=10, maxit=150, tol=1e-5, exit_tol=1e-3, nthread
     stats = np.zeros((B, NSTATS), dtype=np.int32)
     prm = Params(batch.rho, 1.5, getattr(batch, 'mu', 1.0), tol, exit_tol, maxit)
     cnt, dt, xi = _f64(batch.cnt_plan), _f64(batch.dt), _f64(batch.x_init)
-    ndiv = lib().orc_biconvex_solve_batch(B, H, E, C.c_double(batch.m), C.byref(prm), _p(cnt), _p(dt),
+    fn = lib().orc_fast_solve_batch if fast else lib().orc_biconvex_solve_batch
+    ndiv = fn(B, H, E, C.c_double(batch.m), C.byref(prm), _p(cnt), _p(dt),
                                           _p(xi), _p(Qx), _p(qx), _p(Qf), None, _p(lbx), _p(ubx), 0,
                                           _p(X), _p(F), _p(P), _p(Lx), _p(Lf), num_iters, _p(stats),
                                           nthreads)

@@ -175,3 +175,19 @@ def test_gait_phase_functions(oracle):
     assert [lib.orc_gait_phase(0.0, 0.5, 0.6, o) for o in (0.0, 0.5, 0.5, 0.0)] == [1, 1, 1, 1]
     # phi == stance_time within 1e-4 counts as stance (gait_planner.cpp:49)
     assert lib.orc_gait_phase(0.30005, 0.5, 0.6, 0.0) == 1 and lib.orc_gait_phase(0.3002, 0.5, 0.6, 0.0) == 0
+
+
+def test_matrix_free_cpu_variant_agrees_with_the_strict_restatement(oracle):
+    """oracle/biconvex_fast.c (bench.py's second CPU baseline): same iterates and the same discrete path as the
+    explicit-Hessian restatement wherever the iteration is not chaotic (trot), the usual envelope elsewhere"""
+    b = problems.make_batch("solo12_trot", 24)
+    a = oracle.solve_batch(b, num_iters=10)
+    f = oracle.solve_batch(b, num_iters=10, fast=True)
+    assert np.array_equal(a["stats"], f["stats"])
+    for k in "XFP":
+        assert np.all(rel_l2(f[k], a[k]) < 1e-12), k
+    b = problems.make_batch("solo12_mixed", 12)
+    a = oracle.solve_batch(b, num_iters=10)
+    f = oracle.solve_batch(b, num_iters=10, fast=True)
+    assert np.array_equal(a["stats"][:, [0, 5]], f["stats"][:, [0, 5]])
+    assert np.all(rel_l2(f["X"], a["X"]) < 5e-3)
