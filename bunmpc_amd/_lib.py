@@ -60,6 +60,15 @@ class InterpBatch(C.Structure):
                 ("rows", C.c_void_p)]
 
 
+class IdBatch(C.Structure):
+    """bmpc_id_batch_t"""
+    _fields_ = ([("n", C.c_long), ("model", C.c_void_p), ("foot_frame", C.c_int * 4), ("kp", C.c_double * 12),
+                 ("kd", C.c_double * 12)] +
+                [(n, C.c_void_p) for n in ("q", "v", "q_des", "v_des", "a_des", "f")] +
+                [(n, C.c_long) for n in ("s_q", "s_v", "s_q_des", "s_v_des", "s_a_des", "s_f")] +
+                [(n, C.c_void_p) for n in ("tau_ff", "tau_fb", "action", "state")])
+
+
 _lib = None
 
 _D = C.c_double
@@ -125,6 +134,7 @@ _SIGS = {
     "bmpc_plan_batch_device": (_I, [_P, _P]),
     "bmpc_wb_plan_batch_device": (_I, [_P, _P]),
     "bmpc_interp_batch_device": (_I, [_P, _P]),
+    "bmpc_id_batch_device": (_I, [_P, _P]),
     "bmpc_ik_set_speculative_below": (_I, [_I]),
     "bmpc_model_create": (_P, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "bmpc_model_destroy": (None, [_P]),

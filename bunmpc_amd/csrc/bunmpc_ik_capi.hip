@@ -3,6 +3,7 @@
 // ISL/src/motion_planner/kino_dyn.cpp; all numerics run in ik_ddp.hip / biconvex_admm.hip.
 #include "../../include/bunmpc.h"
 #include "ik_types.h"
+#include "id_types.h"
 
 namespace bunmpc {
 int launch_wb_plan(const RobotModelDev *model, const bmpc_wb_plan_batch_t &d, hipStream_t st);   // plan_gen.hip
@@ -265,6 +266,37 @@ int bmpc_wb_plan_batch_device(const bmpc_wb_plan_batch_t *d, void *hip_stream) {
     if (int rc = m->upload()) return rc;
     return bunmpc::launch_wb_plan(m->dptr(), *d, static_cast<hipStream_t>(hip_stream));
 }
+int bmpc_id_batch_device(const bmpc_id_batch_t *d, void *hip_stream) {
+    using namespace bunmpc;
+    if (!d || !d->model) return ik_fail(BMPC_BAD_ARG, "null descriptor or model");
+    if (d->n < 0) return ik_fail(BMPC_BAD_ARG, "n < 0");
+    if (d->n > 0 && (!d->q_des || !d->v_des || !d->a_des || !d->f)) return ik_fail(BMPC_BAD_ARG, "missing desired-state / force array");
+    if ((d->q == nullptr) != (d->v == nullptr)) return ik_fail(BMPC_BAD_ARG, "q and v must be given together");
+    if (d->n > 0 && !d->tau_ff && !d->tau_fb && !d->action && !d->state) return ik_fail(BMPC_BAD_ARG, "no output array");
+    for (int i = 0; i < 12; ++i)
+        if (d->action && d->kp[i] == 0.0) return ik_fail(BMPC_BAD_ARG, "kp = 0 with the pd_target action asked for");
+    IdLaunch a;
+    a.d = *d;
+    if (!d->q) { a.d.q = d->q_des; a.d.v = d->v_des; a.d.s_q = d->s_q_des; a.d.s_v = d->s_v_des; }
+    const RobotModelDev &h = d->model->host;
+    for (int L = 0; L < 4; ++L) { a.leg_foot[L] = -1; a.leg_foot_k[L] = 0; a.leg_foot_p[L][0] = a.leg_foot_p[L][1] = a.leg_foot_p[L][2] = 0.0; }
+    for (int j = 0; j < 4; ++j) {
+        const int f = d->foot_frame[j];
+        if (f < 0 || f >= h.nframes) return ik_fail(BMPC_BAD_ARG, "foot frame out of range");
+        const int body = h.frame_body[f];
+        if (body < 1) return ik_fail(BMPC_BAD_ARG, "an end effector on the base: each must hang off a leg");
+        const int L = (body - 1) / 3;
+        if (a.leg_foot[L] >= 0) return ik_fail(BMPC_BAD_ARG, "two end effectors on one leg");
+        a.leg_foot[L] = j; a.leg_foot_k[L] = (body - 1) % 3;
+        for (int c = 0; c < 3; ++c) a.leg_foot_p[L][c] = h.frame_p[f][c];
+    }
+    if (d->n == 0) return BMPC_OK;
+    bmpc_model *m = const_cast<bmpc_model *>(d->model);
+    if (int rc = m->upload()) return rc;
+    a.model = m->dptr();
+    return launch_id_batch(a, static_cast<hipStream_t>(hip_stream));
+}
+
 int bmpc_ik_set_speculative_below(int n_active) { const int old = g_spec_line_search_below; g_spec_line_search_below = n_active; return old; }
 double bmpc_model_total_mass(const bmpc_model_t *m) { return m ? m->host.total_mass : 0.0; }
 

@@ -311,6 +311,29 @@ typedef struct {
 } bmpc_interp_batch_t;
 int bmpc_interp_batch_device(const bmpc_interp_batch_t *d, void *hip_stream);
 
+/* Output stage of the data path: InverseDynamicsController.id_joint_torques
+ * (ISL/examples/controllers/robot_id_controller.py:57-86) and the rows the rollout loop records from it
+ * (ISL/examples/iterative_algorithm/simulation.py:484-528), for n samples at once, on the device:
+ *   tau_ff = (rnea(q_des, v_des, a_des) - sum_j J_j(q_des)^T [f_j; 0])[6:]
+ *   tau_fb = -kp (q[7:] - q_des[7:]) - kd (v[6:] - v_des[6:])
+ *   action = (tau_ff + tau_fb + kd v[6:]) / kp + q[7:]                     (action_type "pd_target")
+ *   state  = [v (18) | q[0:2] - foot_j[0:2], j < 4 (8) | q[2:] (17)]        (43 doubles)
+ * Every input is a device array of rows with its own row stride in doubles, so the rows of the 1 kHz plan
+ * (xs_int: q at +0, v at +19, stride 37; us_int; f_int) can be passed in place.  q / v NULL = the desired rows
+ * (a sample exactly on its plan: tau_fb = 0).  Outputs are dense ([n][12], [n][43]); NULL ones are skipped.
+ * Each end effector must hang off a different leg. */
+typedef struct {
+    long n;
+    const bmpc_model_t *model;
+    int foot_frame[4];                 /* frame indices of the end effectors, in the order of f */
+    double kp[12], kd[12];
+    const double *q, *v;               /* measured state: rows of 19 / 18 */
+    const double *q_des, *v_des, *a_des, *f;   /* rows of 19 / 18 / 18 / 12 */
+    long s_q, s_v, s_q_des, s_v_des, s_a_des, s_f;
+    double *tau_ff, *tau_fb, *action, *state;
+} bmpc_id_batch_t;
+int bmpc_id_batch_device(const bmpc_id_batch_t *d, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif
