@@ -69,6 +69,14 @@ class IdBatch(C.Structure):
                 [(n, C.c_void_p) for n in ("tau_ff", "tau_fb", "action", "state")])
 
 
+class PerturbBatch(C.Structure):
+    """bmpc_perturb_batch_t"""
+    _fields_ = ([("B", C.c_int), ("K", C.c_int), ("model", C.c_void_p), ("foot_frame", C.c_int * 4), ("mu", C.c_double * 4),
+                 ("sigma", C.c_double * 4), ("q", C.c_void_p), ("v", C.c_void_p), ("contact", C.c_void_p),
+                 ("s_contact_b", C.c_long), ("s_contact_e", C.c_long)] +
+                [(n, C.c_void_p) for n in ("z", "q_out", "v_out", "chosen")])
+
+
 _lib = None
 
 _D = C.c_double
@@ -135,6 +143,7 @@ _SIGS = {
     "bmpc_wb_plan_batch_device": (_I, [_P, _P]),
     "bmpc_interp_batch_device": (_I, [_P, _P]),
     "bmpc_id_batch_device": (_I, [_P, _P]),
+    "bmpc_perturb_batch_device": (_I, [_P, _P]),
     "bmpc_ik_set_speculative_below": (_I, [_I]),
     "bmpc_model_create": (_P, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "bmpc_model_destroy": (None, [_P]),

@@ -4,6 +4,7 @@
 #include "../../include/bunmpc.h"
 #include "ik_types.h"
 #include "id_types.h"
+#include "perturb_types.h"
 
 namespace bunmpc {
 int launch_wb_plan(const RobotModelDev *model, const bmpc_wb_plan_batch_t &d, hipStream_t st);   // plan_gen.hip
@@ -295,6 +296,25 @@ int bmpc_id_batch_device(const bmpc_id_batch_t *d, void *hip_stream) {
     if (int rc = m->upload()) return rc;
     a.model = m->dptr();
     return launch_id_batch(a, static_cast<hipStream_t>(hip_stream));
+}
+
+int bmpc_perturb_batch_device(const bmpc_perturb_batch_t *d, void *hip_stream) {
+    using namespace bunmpc;
+    if (!d || !d->model) return ik_fail(BMPC_BAD_ARG, "null descriptor or model");
+    if (d->B < 0 || d->K < 1) return ik_fail(BMPC_BAD_ARG, "B < 0 or K < 1");
+    for (int j = 0; j < 4; ++j)
+        if (d->foot_frame[j] < 0 || d->foot_frame[j] >= d->model->host.nframes) return ik_fail(BMPC_BAD_ARG, "foot frame out of range");
+    for (int g = 0; g < 4; ++g)
+        if (!(d->sigma[g] >= 0.0)) return ik_fail(BMPC_BAD_ARG, "negative or NaN sigma");
+    if (d->B == 0) return BMPC_OK;
+    if (!d->q || !d->v || !d->contact || !d->z) return ik_fail(BMPC_BAD_ARG, "missing input array");
+    if (!d->q_out || !d->v_out || !d->chosen) return ik_fail(BMPC_BAD_ARG, "missing output array");
+    bmpc_model *m = const_cast<bmpc_model *>(d->model);
+    if (int rc = m->upload()) return rc;
+    PerturbLaunch a;
+    a.d = *d;
+    a.model = m->dptr();
+    return launch_perturb(a, static_cast<hipStream_t>(hip_stream));
 }
 
 int bmpc_ik_set_speculative_below(int n_active) { const int old = g_spec_line_search_below; g_spec_line_search_below = n_active; return old; }

@@ -334,6 +334,30 @@ typedef struct {
 } bmpc_id_batch_t;
 int bmpc_id_batch_device(const bmpc_id_batch_t *d, void *hip_stream);
 
+/* Contact-conditioned perturbation of nominal states: the sampler of the data-collection loop
+ * (ISL/examples/iterative_algorithm/data_collection.py:188-262) for B nominal states at once, on the device.
+ * For state b the draws z[b][0..K) (standard normal, 36 each: 18 for the position, 18 for the velocity perturbation)
+ * are consumed in order until one gives a configuration with no foot below the ground, as the reference's while loop
+ * does: pos = mu + sigma z (mu / sigma = base position, base orientation, joint position, velocity),
+ * q' = integrate(q, (I - pinv(J) J) pos), v' = v + (I - pinv(J * vel) (J * vel)) pos with J the stacked linear
+ * Jacobians of the feet whose contact flag is 1.  chosen[b] = index of the accepted draw, or -1 when all K were
+ * rejected (q_out / v_out then hold the nominal state and the caller draws again for that state).
+ * contact: flag of foot e of state b at contact[b * s_contact_b + e * s_contact_e], so a contact-plan row
+ * (cnt_plan[b][knot][e][0]) can be passed in place. */
+typedef struct {
+    int B, K;
+    const bmpc_model_t *model;
+    int foot_frame[4];
+    double mu[4], sigma[4];
+    const double *q, *v;               /* [B][19], [B][18] nominal states */
+    const double *contact;
+    long s_contact_b, s_contact_e;
+    const double *z;                   /* [B][K][36] */
+    double *q_out, *v_out;             /* [B][19], [B][18] */
+    int *chosen;                       /* [B] */
+} bmpc_perturb_batch_t;
+int bmpc_perturb_batch_device(const bmpc_perturb_batch_t *d, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif
