@@ -170,6 +170,56 @@ def kinodyn_leg(dev, B, admm_iters, maxit, config="solo12_h20", steps=3):
             "admm_diverged": int((r["stats"][:, 5] != 0).sum())}
 
 
+def datagen_leg(dev, B, admm_iters):
+    """Informational: one device-resident pass of the data path around the solve -- perturb B nominal
+    Solo12 states, build their plans, KinoDynMP.optimize, 1 kHz plans, inverse-dynamics labels for the first 50 ms --
+    with the stages timed apart by events (bunmpc_amd/datagen.py)."""
+    import torch
+    from bunmpc_amd import problems, urdf_model
+    from bunmpc_amd.datagen import PlanLabelGenerator
+    from bunmpc_amd.robot_id_controller import id_batch_device
+    model = urdf_model.RobotModel.from_json(open(os.path.join(ROOT, "bunmpc_amd", "robots", "solo12.json")).read())
+    wb = problems.make_wb_batch(model, B)
+    gen = PlanLabelGenerator(model, dyn_iters=admm_iters, device=dev)
+    up = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    # nominal states: the default stance at the batch's phases / desired velocities
+    q = up(np.tile(problems.SOLO12_Q0, (B, 1)))
+    v = torch.zeros((B, 18), dtype=torch.float64, device=dev)
+    t0, vdes = up(wb.dyn.meta["t0"]), up(wb.dyn.meta["v_des_body"])
+    g = torch.Generator(device=dev).manual_seed(7)
+    out = gen.step(q, v, t0, vdes, generator=g)
+    torch.cuda.synchronize(dev)
+    t = time.perf_counter()
+    out = gen.step(q, v, t0, vdes, generator=g)
+    torch.cuda.synchronize(dev)
+    total = time.perf_counter() - t
+    sol = out["solution"]
+    R = out["states"].shape[1]
+
+    def timed(fn, reps=10):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / reps
+    z = torch.randn((B, gen.sampler.K, 36), dtype=torch.float64, device=dev, generator=g)
+    contact = sol["plan"].cnt_plan[:, 0, :, 0]
+    perturb_ms = timed(lambda: gen.sampler.apply(q, v, contact, z))
+    xs = sol["xs_int"][:, :R].reshape(B * R, 37)
+    us = sol["us_int"][:, :R].reshape(B * R, 18)
+    f = sol["f_int"][:, :R].reshape(B * R, 12)
+    id_ms = timed(lambda: id_batch_device(gen.mpc.dm, gen.foot_frames, gen.kp, gen.kd, xs[:, :19], xs[:, 19:], us, f, want=("action", "state")))
+    id_bytes = B * R * ((37 + 18 + 12 + 37) + (12 + 43)) * 8
+    return {"workload": "solo12 trot: perturb -> plan -> KinoDynMP.optimize -> 1 kHz plan -> ID labels", "batch": B,
+            "label_rows": B * R, "ms_per_pass": total * 1e3, "label_rows_per_s": B * R / total,
+            "perturb_kernel_ms": perturb_ms, "rejected_states": int(out["rejected"].numel()),
+            "id_kernel_ms": id_ms, "id_rows_per_s": B * R / id_ms * 1e3, "id_algorithmic_GBps": id_bytes / id_ms / 1e6,
+            "id_frac_of_hbm_peak": id_bytes / id_ms / 1e6 / 8000.0}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -283,6 +333,7 @@ def main():
             out["kinodyn_full_solve"] = kinodyn_leg(dev, args.kinodyn_batch, args.admm_iters, args.maxit, args.kinodyn_config)
             if args.kinodyn_config == "solo12_h20":   # BASELINE config 5's shape as well (1024 problems = its per-GPU share)
                 out["kinodyn_go2_h60"] = kinodyn_leg(dev, 1024, args.admm_iters, args.maxit, "go2_h60")
+                out["datagen_pass"] = datagen_leg(dev, args.kinodyn_batch, args.admm_iters)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

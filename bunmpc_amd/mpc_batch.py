@@ -35,10 +35,10 @@ class BatchedMpc:
         self._kb = None
 
     def optimize(self, x, t0, v_des_body):
-        """x (B,37), t0 (B,), v_des_body (B,3) numpy -> dict of device tensors: xs_int (B,R,37), us_int (B,R,18),
+        """x (B,37), t0 (B,), v_des_body (B,3) numpy arrays or device tensors -> dict of device tensors: xs_int (B,R,37), us_int (B,R,18),
         f_int (B,R,12), rows (B,) valid rows of each, plus the raw solution (xs, us, X, F)"""
         import torch
-        x = np.array(x, dtype=np.float64)
+        x = x.clone() if isinstance(x, torch.Tensor) else np.array(x, dtype=np.float64)
         x[:, 0:2] = 0.0                                                                                    # :633
         B = x.shape[0]
         plan = DeviceWbPlan(self.dm, self.gait, self.offsets_xy, self.wb.feet, self.ik, x, t0, v_des_body, self.H, self.T,

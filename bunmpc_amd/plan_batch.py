@@ -72,10 +72,12 @@ class DeviceWbPlan:
         self.torch, self.device = torch, torch.device(device)
         f64 = torch.float64
 
-        def up(a):
+        def up(a):      # numpy arrays are uploaded, device tensors are taken as they are
+            if isinstance(a, torch.Tensor):
+                return a.to(device=self.device, dtype=f64).contiguous()
             return torch.as_tensor(np.ascontiguousarray(a), dtype=f64, device=self.device).contiguous()
 
-        B = int(np.shape(x)[0])
+        B = int(x.shape[0])
         self.B, self.H, self.T = B, H, T
         raw = (_lib.GaitParams * 1)(gait_struct(gait, offsets_xy))
         self.gait = torch.frombuffer(bytearray(bytes(raw)), dtype=torch.uint8).to(self.device)
