@@ -115,7 +115,10 @@ def pmc_traffic(workload_key):
         return None
 
 
-def kinodyn_leg(dev, B, admm_iters, maxit, config="solo12_h20", steps=3):
+_POOLS = {}
+
+
+def kinodyn_leg(dev, B, admm_iters, maxit, config="solo12_h20", steps=3, n_streams=3):
     """Informational: the full KinoDynMP.optimize (centroidal ADMM + whole-body IK-DDP) over B perturbed
     whole-body states, device resident.  solo12_h20: Solo12 trot, H = 20, H_ik = 10;
     go2_h60: BASELINE config 5's shape (synthetic Go2, trot, H = 60, H_ik = 30)."""
@@ -144,6 +147,25 @@ def kinodyn_leg(dev, B, admm_iters, maxit, config="solo12_h20", steps=3):
     torch.cuda.synchronize(dev)
     dt_ik = (time.perf_counter() - t1) / steps
     r = kb.results()
+    # n_streams batches in flight on as many HIP streams, one host thread each (bunmpc_amd/pipeline.py): the tail
+    # iterations of one batch -- a few stragglers, most of the chip idle -- overlap the bulk phases of the others.
+    # Whole-job throughput of a generator that keeps several batches going.
+    from bunmpc_amd.pipeline import StreamPool
+    kbs = [kb] + [KinoDynDeviceBatch(wb, model, device=dev, num_iters=admm_iters, maxit=maxit) for _ in range(n_streams - 1)]
+    for k in kbs[1:]:
+        k.solve()
+    torch.cuda.synchronize(dev)
+    if n_streams not in _POOLS:    # one pool per run: HIP spreads streams over a few hardware queues, and new streams per
+        _POOLS[n_streams] = StreamPool(dev, n_streams)       # leg can land on one queue and serialise
+    t3 = time.perf_counter()
+    _POOLS[n_streams].run([k.solve for _ in range(steps) for k in kbs])
+    torch.cuda.synchronize(dev)
+    dt2 = (time.perf_counter() - t3) / steps
+    same = True
+    for k in kbs[1:]:
+        r2 = k.results()
+        same = same and bool(np.array_equal(r2["xs"], r["xs"]) and np.array_equal(r2["ik_iters"], r["ik_iters"]))
+    del kbs
     # the inputs of the same batch built on the device from the raw states (bmpc_wb_plan_batch_device)
     plan_ms = None
     if config == "solo12_h20":
@@ -165,6 +187,8 @@ def kinodyn_leg(dev, B, admm_iters, maxit, config="solo12_h20", steps=3):
     return {"value": B / dt, "unit": "KinoDynMP solves/s", "workload": "%s H=%d H_ik=%d" % (config, wb.dyn.H, wb.ik_T),
             "device_built_inputs_ms": plan_ms,
             "batch": B, "ms_per_step": dt * 1e3,
+            "multi_stream": {"streams": n_streams, "value": n_streams * B / dt2, "unit": "KinoDynMP solves/s",
+                             "ms_per_round_of_batches": dt2 * 1e3, "results_equal_single_stream": same},
             "ik_only_ms_per_step": dt_ik * 1e3, "ddp_iters_mean": float(r["ik_iters"].mean()),
             "ddp_iters_max": int(r["ik_iters"].max()), "ddp_not_converged": int((r["ik_status"] != 0).sum()),
             "admm_diverged": int((r["stats"][:, 5] != 0).sum())}
@@ -233,6 +257,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-kinodyn", action="store_true")
+    ap.add_argument("--kinodyn-streams", type=int, default=3, help="batches in flight in the multi-stream KinoDyn measurement")
     ap.add_argument("--kinodyn-batch", type=int, default=4096)
     ap.add_argument("--kinodyn-config", default="solo12_h20", choices=["solo12_h20", "go2_h60"],
                     help="solo12_h20: Solo12 trot H=20 / H_ik=10; go2_h60: BASELINE config 5 (synthetic Go2, H=60 / H_ik=30)")
@@ -330,9 +355,9 @@ def main():
         if world == 1 and not args.no_latency:
             out["p50_latency_ms_batch1"] = p50_latency(args.config, args.admm_iters)
         if world == 1 and not args.no_kinodyn:
-            out["kinodyn_full_solve"] = kinodyn_leg(dev, args.kinodyn_batch, args.admm_iters, args.maxit, args.kinodyn_config)
+            out["kinodyn_full_solve"] = kinodyn_leg(dev, args.kinodyn_batch, args.admm_iters, args.maxit, args.kinodyn_config, n_streams=args.kinodyn_streams)
             if args.kinodyn_config == "solo12_h20":   # BASELINE config 5's shape as well (1024 problems = its per-GPU share)
-                out["kinodyn_go2_h60"] = kinodyn_leg(dev, 1024, args.admm_iters, args.maxit, "go2_h60")
+                out["kinodyn_go2_h60"] = kinodyn_leg(dev, 1024, args.admm_iters, args.maxit, "go2_h60", n_streams=args.kinodyn_streams)
                 out["datagen_pass"] = datagen_leg(dev, args.kinodyn_batch, args.admm_iters)
         print(json.dumps(out))
     if world > 1:
