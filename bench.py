@@ -354,6 +354,13 @@ def main():
             out["speedup_vs_matrix_free_cpu"] = out["value"] / out["cpu_baseline"]["matrix_free_variant"]["value"]
         if world == 1 and not args.no_latency:
             out["p50_latency_ms_batch1"] = p50_latency(args.config, args.admm_iters)
+            # the same batch through the host-buffer entry point (pageable numpy arrays in, H2D, one launch, D2H):
+            # the PCIe-inclusive rate -- reported beside `value`, never as it
+            bb.solve_host(pb, num_iters=args.admm_iters, maxit=args.maxit, precision=args.precision)
+            th = time.perf_counter()
+            for _ in range(3):
+                bb.solve_host(pb, num_iters=args.admm_iters, maxit=args.maxit, precision=args.precision)
+            out["host_buffers_solves_per_s"] = 3 * B / (time.perf_counter() - th)
         if world == 1 and not args.no_kinodyn:
             out["kinodyn_full_solve"] = kinodyn_leg(dev, args.kinodyn_batch, args.admm_iters, args.maxit, args.kinodyn_config, n_streams=args.kinodyn_streams)
             if args.kinodyn_config == "solo12_h20":   # BASELINE config 5's shape as well (1024 problems = its per-GPU share)

@@ -26,6 +26,7 @@ class DeviceModel:
         arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in
                 (model.R.reshape(model.nj, 9), model.p, model.axis, model.mass, model.com, model.inertia.reshape(-1, 9))]
         parent = np.ascontiguousarray(model.parent, dtype=np.int32)
+        self._destroy = lib.bmpc_model_destroy
         self.h = lib.bmpc_model_create(model.nj, parent.ctypes.data, *[a.ctypes.data for a in arrs], len(fr),
                                        fbody.ctypes.data, fp.ctypes.data)
         if not self.h:
@@ -34,7 +35,7 @@ class DeviceModel:
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
         if h:
-            _lib.lib().bmpc_model_destroy(h)
+            self._destroy(h)       # bound at construction: module globals may be gone at interpreter exit
 
 
 def as_device_model(m):
