@@ -408,6 +408,43 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a
 // transposition later it holds row r of N and finishes row r of G = N F_x, again lane-locally.
 constexpr int LD = kNDX + 1;   // odd leading dimension: rows and columns of 64-bit words are both conflict-free
 constexpr int LDU = kNV + 1;
+// The Schur update V_xx = Q_xx - Q_xu K runs on the matrix pipe as 3 x 3 tiles of v_mfma_f64_16x16x4 (36 -> 48, k: 18 -> 20).
+// Operand images in LDS: -Q_xu and K^T as [48][LDK] (zero outside 36 x 18, so the padding contributes nothing), Q_xx / V_xx
+// in the rows of N ([48][LD]: the padded rows are read and written but never used).  Lane l holds A[l & 15][k = l >> 4],
+// B[k = l >> 4][l & 15] and D[(l >> 4) + 4 v][l & 15], v < 4; every element a lane touches sits at a compile-time offset
+// from one per-lane base address, so the reads are batches of ds_read_b64 with immediate offsets (lds_batch.h explains
+// why they are asm: hipcc puts a full wait after each LDS read it schedules itself).
+constexpr int LDK = 21, kPadRows = 48;
+typedef double mfma_acc_t __attribute__((ext_vector_type(4)));
+#define BWD_STR2(x) #x
+#define BWD_STR(x) BWD_STR2(x)
+#define BWD_OFFK(I, ks) ((16 * I * 21 + 4 * ks) * 8)
+#define BWD_OFFN(I, J, v) (((16 * I + 4 * v) * 37 + 16 * J) * 8)
+#define BWD_RDK(n, I, ks) "ds_read_b64 %" #n ", %15 offset:" BWD_STR(BWD_OFFK(I, ks)) "\n"
+#define BWD_RDN(n, I, J, v) "ds_read_b64 %" #n ", %12 offset:" BWD_STR(BWD_OFFN(I, J, v)) "\n"
+// o[5 I + ks] = image[16 I + (l & 15)][4 ks + (l >> 4)]
+__device__ __forceinline__ void lds_read_mfma_operand(unsigned base, double (&o)[15]) {
+    asm volatile(BWD_RDK(0, 0, 0) BWD_RDK(1, 0, 1) BWD_RDK(2, 0, 2) BWD_RDK(3, 0, 3) BWD_RDK(4, 0, 4)
+                 BWD_RDK(5, 1, 0) BWD_RDK(6, 1, 1) BWD_RDK(7, 1, 2) BWD_RDK(8, 1, 3) BWD_RDK(9, 1, 4)
+                 BWD_RDK(10, 2, 0) BWD_RDK(11, 2, 1) BWD_RDK(12, 2, 2) BWD_RDK(13, 2, 3) BWD_RDK(14, 2, 4)
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+                   "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14])
+                 : "v"(base) : "memory");
+}
+// the accumulator tiles (I, 0..2) of lane l: o[4 J + v] = N[16 I + (l >> 4) + 4 v][16 J + (l & 15)]
+#define BWD_TILE_ROW(I) \
+    asm volatile(BWD_RDN(0, I, 0, 0) BWD_RDN(1, I, 0, 1) BWD_RDN(2, I, 0, 2) BWD_RDN(3, I, 0, 3) \
+                 BWD_RDN(4, I, 1, 0) BWD_RDN(5, I, 1, 1) BWD_RDN(6, I, 1, 2) BWD_RDN(7, I, 1, 3) \
+                 BWD_RDN(8, I, 2, 0) BWD_RDN(9, I, 2, 1) BWD_RDN(10, I, 2, 2) BWD_RDN(11, I, 2, 3) \
+                 "s_waitcnt lgkmcnt(0)" \
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), \
+                   "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]) \
+                 : "v"(base) : "memory")
+template <int I>
+__device__ __forceinline__ void lds_read_mfma_acc_row(unsigned base, double (&o)[12]) {
+    if (I == 0) BWD_TILE_ROW(0); else if (I == 1) BWD_TILE_ROW(1); else BWD_TILE_ROW(2);
+}
 
 // value of v in lane `src` (compile-time constant), wave-uniform: two v_readlane_b32
 __device__ __forceinline__ double lane_value(double v, int src) {
@@ -421,8 +458,9 @@ __device__ __forceinline__ double rcp64(double b) {
 }
 
 struct alignas(16) BackwardLds {
-    double N[kNDX * LD];       // row-major staging: N = F_x^T V for the transposition, later Q_xx -> V_xx rows
-    double Kt[kNDX * kNV];     // K^T: column j of K contiguous at Kt[18 j], read back by broadcast
+    double N[kPadRows * LD + 16];   // row-major staging: N = F_x^T V for the transposition, later Q_xx -> V_xx rows
+    double Kt[kPadRows * LDK];      // K^T (36 x 18 in a zeroed 48 x 21 image): the B operand of the Schur update's MFMA tiles
+    double Qs[kPadRows * LDK];      // -Q_xu in the same layout: the A operand
     double Lr[5 * 36], Lc[5 * 36];   // Cholesky factor packed by rows (L[p][q], q < p, at p(p-1)/2 + q) and by columns
                                      // (L[q][p], q > p, at p(35-p)/2 + q-p-1), read back by broadcast in batches of 36
     double A6[36], B6[36];
@@ -460,6 +498,8 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
     const int T = a.T;
     bool feas = sc[S_FEAS] != 0.0;
     const bool wasfeas = sc[S_WASFEAS] != 0.0;
+    for (int i = lane; i < kPadRows * LDK; i += 64) { s.Kt[i] = 0.0; s.Qs[i] = 0.0; }     // the padding of the MFMA operand images
+    for (int i = kNDX * LD + lane; i < kPadRows * LD + 16; i += 64) s.N[i] = 0.0;
 
     if (sc[S_RECALC] != 0.0) {
         // SolverDDP::calcDiff tail: total cost and the gaps fs
@@ -612,7 +652,7 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             UNROLL_RBD for (int p = 0; p < kNV; ++p) { d1 += quv[p] * y[p]; st += quv[p] * quv[p]; }   // d1 = Qu.k, stop = |Qu|^2
             double *Ks = s.Kt;
             if (row) {
-                UNROLL_RBD for (int p = 0; p < kNV; ++p) { Ks[r * kNV + p] = y[p]; ws[L.K + (long)t * kNV * kNDX + (long)p * kNDX + r] = y[p]; }
+                UNROLL_RBD for (int p = 0; p < kNV; ++p) { Ks[r * LDK + p] = y[p]; s.Qs[r * LDK + p] = -qxu[p]; ws[L.K + (long)t * kNV * kNDX + (long)p * kNDX + r] = y[p]; }
             } else if (lane == kNDX) {
                 UNROLL_RBD for (int p = 0; p < kNV; ++p) ws[L.kff + (long)t * kNV + p] = y[p];
             }
@@ -624,22 +664,32 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             }
             __syncthreads();
             PSTAMPV(6, vx)
-            // V_xx = Q_xx - Q_xu K, row r, in its LDS row: the column loop is a real loop (36 x 18 fused multiply-adds
-            // against broadcast reads of K^T; unrolled over all j the scheduler hoists every read and spills)
+            // V_xx = Q_xx - Q_xu K on the matrix pipe (layouts at BackwardLds): fp64 MFMA has the vector FMA rate on gfx950, so
+            // this is not about flops -- one MFMA replaces 16 wave-wide FMAs in the issue stream, and every lane feeds ONE
+            // element of -Q_xu and of K^T per step instead of all lanes reading all of K^T by broadcast (66 ds_read_b64 per
+            // lane against 342 ds_read_b128).  Nine independent accumulators, k outermost, keep the pipe fed.
             {
-                const unsigned kaddr = lds_offset(Ks);
-                for (int j0 = 0; j0 < kNDX; j0 += 4) {      // four columns per trip: their 36 K^T reads in two back-to-back batches
-                    double2_t ka[18], kb[18], wr[2];
-                    lds_read_b128x18_and4(kaddr + (unsigned)j0 * (kNV * 8), row_addr + (unsigned)j0 * 8, ka, wr);   // + own row entries
-                    lds_read_b128x18(kaddr + (unsigned)(j0 + 2) * (kNV * 8), kb);
-                    double w0 = wr[0].x, w1 = wr[0].y, w2 = wr[1].x, w3 = wr[1].y;
-                    UNROLL_RBD for (int p = 0; p < 9; ++p) {
-                        w0 -= qxu[2 * p] * ka[p].x; w1 -= qxu[2 * p] * ka[9 + p].x; w2 -= qxu[2 * p] * kb[p].x; w3 -= qxu[2 * p] * kb[9 + p].x;
-                        w0 -= qxu[2 * p + 1] * ka[p].y; w1 -= qxu[2 * p + 1] * ka[9 + p].y; w2 -= qxu[2 * p + 1] * kb[p].y; w3 -= qxu[2 * p + 1] * kb[9 + p].y;
-                    }
-                    if (row) { s.N[r * LD + j0] = w0; s.N[r * LD + j0 + 1] = w1; s.N[r * LD + j0 + 2] = w2; s.N[r * LD + j0 + 3] = w3; }
-                }
+                const int li = lane & 15, lk = lane >> 4;
+                double av[15], bv[15], c0[12], c1[12], c2[12];
+                lds_read_mfma_operand(lds_offset(s.Qs + li * LDK + lk), av);
+                lds_read_mfma_operand(lds_offset(Ks + li * LDK + lk), bv);
+                const unsigned nbase = lds_offset(s.N + lk * LD + li);
+                lds_read_mfma_acc_row<0>(nbase, c0);
+                lds_read_mfma_acc_row<1>(nbase, c1);
+                lds_read_mfma_acc_row<2>(nbase, c2);
+                mfma_acc_t acc[9];
+                UNROLL_RBD for (int J = 0; J < 3; ++J)
+                    UNROLL_RBD for (int v = 0; v < 4; ++v) { acc[J][v] = c0[4 * J + v]; acc[3 + J][v] = c1[4 * J + v]; acc[6 + J][v] = c2[4 * J + v]; }
+                UNROLL_RBD for (int ks = 0; ks < 5; ++ks)
+                    UNROLL_RBD for (int I = 0; I < 3; ++I)
+                        UNROLL_RBD for (int J = 0; J < 3; ++J)
+                            acc[3 * I + J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[5 * I + ks], bv[5 * J + ks], acc[3 * I + J], 0, 0, 0);
+                UNROLL_RBD for (int I = 0; I < 3; ++I)
+                    UNROLL_RBD for (int J = 0; J < 3; ++J)
+                        if (J < 2 || li < kNDX - 32)       // columns 36..47 do not exist (rows 36..47 do, as padding)
+                            UNROLL_RBD for (int v = 0; v < 4; ++v) s.N[(16 * I + lk + 4 * v) * LD + 16 * J + li] = acc[3 * I + J][v];
             }
+            __syncthreads();
             PSTAMPV(7, vx)
             // V = (V_xx + V_xx^T)/2 + xreg I: own row and own column of the staged V_xx (xreg added to the staged diagonal)
             if (row) s.N[r * LD + r] += xreg;
