@@ -28,6 +28,7 @@ class PlanLabelGenerator:
         self.foot_frames = [model.frame_id(n) for n in wb.feet]
         self.kp, self.kd, self.gait, self.wb = kp, kd, gait, wb
         self.rows_per_plan = int(round(planning_time / 0.001))
+        self._nominal = None
 
     def step(self, q_nom, v_nom, t0, v_des_body, generator=None, perturb=True):
         """q_nom (B,19), v_nom (B,18), t0 (B,), v_des_body (B,3): device tensors.  Returns device tensors
@@ -41,7 +42,11 @@ class PlanLabelGenerator:
         if perturb:
             x = torch.cat([q_nom, v_nom], dim=1)
             x[:, 0:2] = 0.0
-            nominal = DeviceWbPlan(m.dm, m.gait, m.offsets_xy, m.wb.feet, m.ik, x, t0, v_des_body, m.H, m.T, device=m.device).build()
+            if self._nominal is not None and self._nominal.B == B:
+                nominal = self._nominal.update(x, t0, v_des_body).build()
+            else:
+                nominal = self._nominal = DeviceWbPlan(m.dm, m.gait, m.offsets_xy, m.wb.feet, m.ik, x, t0, v_des_body, m.H, m.T,
+                                                       device=m.device).build()
             q0, v0, rejected = self.sampler.sample(q_nom, v_nom, nominal.cnt_plan[:, 0, :, 0], generator=generator)
         else:
             q0, v0 = q_nom, v_nom

@@ -32,19 +32,24 @@ class BatchedMpc:
         offs = np.round(fk_np.frame_positions(model, k0, wb.hips)[0] - k0["com"][0], 3)                     # :56-59
         offs[:, 1] += np.array([0.04, -0.04, 0.04, -0.04])                                                 # :61-72
         self.offsets_xy = offs[:, :2]
-        self._kb = None
+        self._kb = self._plan = None
 
     def optimize(self, x, t0, v_des_body):
         """x (B,37), t0 (B,), v_des_body (B,3) numpy arrays or device tensors -> dict of device tensors: xs_int (B,R,37), us_int (B,R,18),
-        f_int (B,R,12), rows (B,) valid rows of each, plus the raw solution (xs, us, X, F)"""
+        f_int (B,R,12), rows (B,) valid rows of each, plus the raw solution (xs, us, X, F).  The raw solution and `plan` are
+        views of buffers the next call with the same batch size reuses: copy what has to outlive it."""
         import torch
         x = x.clone() if isinstance(x, torch.Tensor) else np.array(x, dtype=np.float64)
         x[:, 0:2] = 0.0                                                                                    # :633
         B = x.shape[0]
-        plan = DeviceWbPlan(self.dm, self.gait, self.offsets_xy, self.wb.feet, self.ik, x, t0, v_des_body, self.H, self.T,
-                            device=self.device).build()
-        wbb = self._weights_only_batch(B, x)
-        kb = KinoDynDeviceBatch(wbb, self.model, device=self.device, num_iters=self.dyn_iters, plan=plan)
+        if self._kb is not None and self._kb.wb.dyn.B == B:
+            # same batch size as the last call: the plan tensors, the solver's workspace and its descriptors are reused
+            plan, kb = self._plan, self._kb
+            plan.update(x, t0, v_des_body).build()
+        else:
+            plan = DeviceWbPlan(self.dm, self.gait, self.offsets_xy, self.wb.feet, self.ik, x, t0, v_des_body, self.H, self.T,
+                                device=self.device).build()
+            kb = KinoDynDeviceBatch(self._weights_only_batch(B), self.model, device=self.device, num_iters=self.dyn_iters, plan=plan)
         kb.solve()
         T, H = self.T, self.H
         o = kb.off
@@ -54,16 +59,17 @@ class BatchedMpc:
         xs_int, rows = interpolate_on_device(xs, plan.dt, self.size)
         us_int, _ = interpolate_on_device(us, plan.dt, self.size)
         f_int, _ = interpolate_on_device(F, plan.dt, self.size)
-        self._kb = kb
+        self._kb, self._plan = kb, plan
         return dict(xs_int=xs_int, us_int=us_int, f_int=f_int, rows=rows, xs=xs, us=us, X=kb.dyn.X, F=kb.dyn.F, plan=plan)
 
-    def _weights_only_batch(self, B, x):
-        """the small host-provided part of a WholeBodyBatch: weights, bounds, regularisation reference"""
+    def _weights_only_batch(self, B):
+        """the small host-provided part of a WholeBodyBatch: weights, bounds, regularisation reference (the per-problem
+        arrays come from the device plan: placeholders of the right type here, never uploaded)"""
         g, ik, H = self.gait, self.ik, self.H
-        z = np.zeros
-        dyn = problems.Batch(self.wb.name + "_mpc", B, H, 4, self.model.total_mass, g.rho, z((B, H, 4, 4)), z((B, H)), z((B, 9)),
-                             z((B, 9 * H)), z((B, 9)), np.tile(g.W_X, H)[None], g.W_X_ter[None].copy(), np.tile(g.W_F, H)[None],
+        z = lambda *shape: np.broadcast_to(0.0, shape)       # noqa: E731 -- shape-only stand-ins, no memory behind them
+        dyn = problems.Batch(self.wb.name + "_mpc", B, H, 4, self.model.total_mass, g.rho, z(B, H, 4, 4), z(B, H), z(B, 9),
+                             z(B, 9 * H), z(B, 9), np.tile(g.W_X, H)[None], g.W_X_ter[None].copy(), np.tile(g.W_F, H)[None],
                              np.tile(problems.BOUNDS_TILE, (H, 1))[None], None, None, self.wb.mu, {})
         x_reg = np.concatenate([np.tile(self.wb.q0, (B, 1)), np.zeros((B, 18))], axis=1)
-        return problems.WholeBodyBatch(dyn, x, self.T, z((B, self.T + 1, 33)), ik["state_wt"][None].copy(), ik["ctrl_wt"][None].copy(),
+        return problems.WholeBodyBatch(dyn, z(B, 37), self.T, z(B, self.T + 1, 33), ik["state_wt"][None].copy(), ik["ctrl_wt"][None].copy(),
                                        x_reg, ik["cent_wt"][0], ik["cent_wt"][1], ())

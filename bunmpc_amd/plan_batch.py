@@ -105,6 +105,14 @@ class DeviceWbPlan:
         self.desc = d
         self.dev_model = dev_model
 
+    def update(self, x, t0, v_des_body):
+        """new states / times / desired velocities for the same batch size, copied into the tensors the descriptor points
+        at (nothing is allocated: the steady state of a generator that plans batch after batch)"""
+        torch = self.torch
+        for dst, src in ((self.x, x), (self.t0, t0), (self.v_des_body, v_des_body)):
+            dst.copy_(src if isinstance(src, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(src), dtype=torch.float64))
+        return self
+
     def build(self):
         stream = self.torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(_lib.lib().bmpc_wb_plan_batch_device(C.byref(self.desc), C.c_void_p(stream)))

@@ -97,6 +97,25 @@ def test_batched_mpc_equals_the_harness_call_by_call():
             assert rel_l2(got.reshape(-1), ref.reshape(-1)) < 1e-7, (i, name)
 
 
+def test_batched_mpc_reuses_its_buffers_without_changing_results():
+    """a second optimize() of the same size runs in the first call's plan tensors / solver workspace (nothing allocated):
+    same result, bit for bit, as a fresh object; device tensors are accepted as inputs"""
+    import torch
+    from bunmpc_amd.mpc_batch import BatchedMpc
+    model = urdf_model.RobotModel.from_json(open(ROBOT).read())
+    wb1, wb2 = problems.make_wb_batch(model, 6, seed=11), problems.make_wb_batch(model, 6, seed=12)
+    mpc = BatchedMpc(model, dyn_iters=10)
+    first = mpc.optimize(wb1.x, wb1.dyn.meta["t0"], wb1.dyn.meta["v_des_body"])
+    keep = first["xs_int"].clone()
+    dev = lambda a: torch.as_tensor(a, dtype=torch.float64, device="cuda:0")
+    again = mpc.optimize(dev(wb2.x), dev(wb2.dyn.meta["t0"]), dev(wb2.dyn.meta["v_des_body"]))
+    fresh = BatchedMpc(model, dyn_iters=10).optimize(wb2.x, wb2.dyn.meta["t0"], wb2.dyn.meta["v_des_body"])
+    for k in ("xs_int", "us_int", "f_int", "rows", "xs", "us", "X", "F"):
+        assert torch.equal(again[k], fresh[k]), k
+    assert not torch.equal(keep, again["xs_int"])
+    assert again["xs"].data_ptr() == first["xs"].data_ptr()      # the workspace was reused
+
+
 def crouch_plan(model):
     """An ACyclicMotionParams-shaped plan (weight_abstract.py:44-80): stand, then crouch -- two phases of nominal height,
     regularisation posture and weights, so the per-node regularisation vectors differ along the horizon."""
