@@ -15,6 +15,7 @@ int launch_wb_plan(const RobotModelDev *model, const bmpc_wb_plan_batch_t &d, hi
 #include <cstring>
 #include <iostream>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -48,7 +49,9 @@ struct bmpc_model {
     bunmpc::RobotModelDev host;
     Dev dev;            // device copy, uploaded lazily
     bool uploaded = false;
+    std::mutex upload_lock;     // batches of several host threads may share one model (bunmpc_amd/pipeline.py)
     int upload() {
+        std::lock_guard<std::mutex> hold(upload_lock);
         if (uploaded) return BMPC_OK;
         HIP_TRY(dev.ensure(sizeof(host)));
         HIP_TRY(hipMemcpy(dev.p, &host, sizeof(host), hipMemcpyHostToDevice));

@@ -408,9 +408,9 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a
 // transposition later it holds row r of N and finishes row r of G = N F_x, again lane-locally.
 constexpr int LD = kNDX + 1;   // odd leading dimension: rows and columns of 64-bit words are both conflict-free
 constexpr int LDU = kNV + 1;
-// The Schur update V_xx = Q_xx - Q_xu K runs on the matrix pipe as 3 x 3 tiles of v_mfma_f64_16x16x4 (36 -> 48, k: 18 -> 20).
-// Operand images in LDS: -Q_xu and K^T as [48][LDK] (zero outside 36 x 18, so the padding contributes nothing), Q_xx / V_xx
-// in the rows of N ([48][LD]: the padded rows are read and written but never used).  Lane l holds A[l & 15][k = l >> 4],
+// The Schur update V_xx = Q_xx - Q_xu K = Q_xx - Y^T Y (Y = L^-1 Q_ux) runs on the matrix pipe as tiles of v_mfma_f64_16x16x4
+// (36 -> 48, k: 18 -> 20).  Operand image in LDS: Y^T as [48][LDK] (zero outside 36 x 18, so the padding contributes nothing),
+// Q_xx / V_xx in the rows of N ([48][LD]: the padded rows are read and written but never used).  Lane l holds A[l & 15][k = l >> 4],
 // B[k = l >> 4][l & 15] and D[(l >> 4) + 4 v][l & 15], v < 4; every element a lane touches sits at a compile-time offset
 // from one per-lane base address, so the reads are batches of ds_read_b64 with immediate offsets (lds_batch.h explains
 // why they are asm: hipcc puts a full wait after each LDS read it schedules itself).
@@ -432,18 +432,23 @@ __device__ __forceinline__ void lds_read_mfma_operand(unsigned base, double (&o)
                    "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14])
                  : "v"(base) : "memory");
 }
-// the accumulator tiles (I, 0..2) of lane l: o[4 J + v] = N[16 I + (l >> 4) + 4 v][16 J + (l & 15)]
-#define BWD_TILE_ROW(I) \
-    asm volatile(BWD_RDN(0, I, 0, 0) BWD_RDN(1, I, 0, 1) BWD_RDN(2, I, 0, 2) BWD_RDN(3, I, 0, 3) \
-                 BWD_RDN(4, I, 1, 0) BWD_RDN(5, I, 1, 1) BWD_RDN(6, I, 1, 2) BWD_RDN(7, I, 1, 3) \
-                 BWD_RDN(8, I, 2, 0) BWD_RDN(9, I, 2, 1) BWD_RDN(10, I, 2, 2) BWD_RDN(11, I, 2, 3) \
-                 "s_waitcnt lgkmcnt(0)" \
-                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), \
-                   "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]) \
-                 : "v"(base) : "memory")
-template <int I>
-__device__ __forceinline__ void lds_read_mfma_acc_row(unsigned base, double (&o)[12]) {
-    if (I == 0) BWD_TILE_ROW(0); else if (I == 1) BWD_TILE_ROW(1); else BWD_TILE_ROW(2);
+// the accumulator tiles on and above the block diagonal, the order the Schur update numbers them in:
+// tile 0..5 = (0,0) (0,1) (0,2) (1,1) (1,2) (2,2);  o[4 tile + v] = N[16 I + (l >> 4) + 4 v][16 J + (l & 15)]
+__device__ __forceinline__ void lds_read_mfma_acc_upper(unsigned base, double (&o)[24]) {
+    asm volatile(BWD_RDN(0, 0, 0, 0) BWD_RDN(1, 0, 0, 1) BWD_RDN(2, 0, 0, 2) BWD_RDN(3, 0, 0, 3)
+                 BWD_RDN(4, 0, 1, 0) BWD_RDN(5, 0, 1, 1) BWD_RDN(6, 0, 1, 2) BWD_RDN(7, 0, 1, 3)
+                 BWD_RDN(8, 0, 2, 0) BWD_RDN(9, 0, 2, 1) BWD_RDN(10, 0, 2, 2) BWD_RDN(11, 0, 2, 3)
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+                   "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11])
+                 : "v"(base) : "memory");
+    asm volatile(BWD_RDN(0, 1, 1, 0) BWD_RDN(1, 1, 1, 1) BWD_RDN(2, 1, 1, 2) BWD_RDN(3, 1, 1, 3)
+                 BWD_RDN(4, 1, 2, 0) BWD_RDN(5, 1, 2, 1) BWD_RDN(6, 1, 2, 2) BWD_RDN(7, 1, 2, 3)
+                 BWD_RDN(8, 2, 2, 0) BWD_RDN(9, 2, 2, 1) BWD_RDN(10, 2, 2, 2) BWD_RDN(11, 2, 2, 3)
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15]), "=&v"(o[16]), "=&v"(o[17]), "=&v"(o[18]), "=&v"(o[19]),
+                   "=&v"(o[20]), "=&v"(o[21]), "=&v"(o[22]), "=&v"(o[23])
+                 : "v"(base) : "memory");
 }
 
 // value of v in lane `src` (compile-time constant), wave-uniform: two v_readlane_b32
@@ -459,8 +464,7 @@ __device__ __forceinline__ double rcp64(double b) {
 
 struct alignas(16) BackwardLds {
     double N[kPadRows * LD + 16];   // row-major staging: N = F_x^T V for the transposition, later Q_xx -> V_xx rows
-    double Kt[kPadRows * LDK];      // K^T (36 x 18 in a zeroed 48 x 21 image): the B operand of the Schur update's MFMA tiles
-    double Qs[kPadRows * LDK];      // -Q_xu in the same layout: the A operand
+    double Ys[kPadRows * LDK];      // Y^T, Y = L^-1 Q_ux (36 x 18 in a zeroed 48 x 21 image): both operands of the Schur update
     double Lr[5 * 36], Lc[5 * 36];   // Cholesky factor packed by rows (L[p][q], q < p, at p(p-1)/2 + q) and by columns
                                      // (L[q][p], q > p, at p(35-p)/2 + q-p-1), read back by broadcast in batches of 36
     double A6[36], B6[36];
@@ -498,7 +502,7 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
     const int T = a.T;
     bool feas = sc[S_FEAS] != 0.0;
     const bool wasfeas = sc[S_WASFEAS] != 0.0;
-    for (int i = lane; i < kPadRows * LDK; i += 64) { s.Kt[i] = 0.0; s.Qs[i] = 0.0; }     // the padding of the MFMA operand images
+    for (int i = lane; i < kPadRows * LDK; i += 64) s.Ys[i] = 0.0;                         // the padding of the MFMA operand image
     for (int i = kNDX * LD + lane; i < kPadRows * LD + 16; i += 64) s.N[i] = 0.0;
 
     if (sc[S_RECALC] != 0.0) {
@@ -634,6 +638,19 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             }
             // expectedImprovement / stoppingCriteria ingredients (lane 36): d2 = -k.Quu k = -|L^T k|^2 = -|L^-1 Qu|^2
             UNROLL_RBD for (int p = 0; p < kNV; ++p) d2 -= y[p] * y[p];
+            // Y = L^-1 Q_ux (column j on lane j) is all the Riccati recursion needs: Q_xu K = Q_xu Q_uu^-1 Q_ux = Y^T Y.  It goes to
+            // LDS as the one operand image of the Schur update; the gains K = L^-T Y (back substitution) are for the forward pass,
+            // not for the next node.  The MFMAs are issued after the substitution (their accumulators would not fit beside its
+            // registers) and before the stores of K, V_x and the improvement terms, which the vector pipe does while the matrix
+            // pipe works through its tiles.
+            if (row) { UNROLL_RBD for (int p = 0; p < kNV; ++p) s.Ys[r * LDK + p] = y[p]; }
+            __syncthreads();
+            // V_xx = Q_xx - Y^T Y on the matrix pipe (layouts at BackwardLds): fp64 MFMA has the vector FMA rate on gfx950, so this
+            // is not about flops -- one MFMA replaces 16 wave-wide FMAs in the issue stream, and every lane feeds ONE element of
+            // Y per step instead of all lanes reading a whole 36 x 18 matrix by broadcast (51 ds_read_b64 per lane against 342
+            // ds_read_b128 of the vector version).  The product is symmetric and V_xx is symmetrised right after: only the six
+            // tiles on and above the block diagonal are computed (independent accumulators, k outermost); an off-diagonal tile is
+            // stored a second time, transposed, where its mirror image belongs.
             {
                 const unsigned lc_addr = lds_offset(s.Lc);
                 double2_t lb[18];
@@ -649,10 +666,25 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
                 }
             }
             PSTAMPV(5, y[0])
+            const int li = lane & 15, lk = lane >> 4;
+            mfma_acc_t acc[6];
+            {
+                double bv[15], c[24];
+                lds_read_mfma_operand(lds_offset(s.Ys + li * LDK + lk), bv);
+                lds_read_mfma_acc_upper(lds_offset(s.N + lk * LD + li), c);
+                UNROLL_RBD for (int tl = 0; tl < 6; ++tl)
+                    UNROLL_RBD for (int v = 0; v < 4; ++v) acc[tl][v] = c[4 * tl + v];
+                UNROLL_RBD for (int ks = 0; ks < 5; ++ks)
+                    UNROLL_RBD for (int I = 0; I < 3; ++I)
+                        UNROLL_RBD for (int J = I; J < 3; ++J) {
+                            const int tl = (I == 0 ? 0 : I == 1 ? 2 : 3) + J;
+                            acc[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-bv[5 * I + ks], bv[5 * J + ks], acc[tl], 0, 0, 0);
+                        }
+            }
             UNROLL_RBD for (int p = 0; p < kNV; ++p) { d1 += quv[p] * y[p]; st += quv[p] * quv[p]; }   // d1 = Qu.k, stop = |Qu|^2
-            double *Ks = s.Kt;
-            if (row) {
-                UNROLL_RBD for (int p = 0; p < kNV; ++p) { Ks[r * LDK + p] = y[p]; s.Qs[r * LDK + p] = -qxu[p]; ws[L.K + (long)t * kNV * kNDX + (long)p * kNDX + r] = y[p]; }
+            if (row) {      // (the empty asm keeps the stores in program order: clustered, hipcc spills a hundred registers around them)
+                double *Kg = ws + L.K + (long)t * kNV * kNDX + r;
+                UNROLL_RBD for (int p = 0; p < kNV; ++p) { Kg[p * kNDX] = y[p]; asm volatile("" ::: "memory"); }
             } else if (lane == kNDX) {
                 UNROLL_RBD for (int p = 0; p < kNV; ++p) ws[L.kff + (long)t * kNV + p] = y[p];
             }
@@ -662,33 +694,17 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
                 UNROLL_RBD for (int p = 0; p < kNV; ++p) w -= y[p] * quv[p];
                 vx = w;
             }
-            __syncthreads();
             PSTAMPV(6, vx)
-            // V_xx = Q_xx - Q_xu K on the matrix pipe (layouts at BackwardLds): fp64 MFMA has the vector FMA rate on gfx950, so
-            // this is not about flops -- one MFMA replaces 16 wave-wide FMAs in the issue stream, and every lane feeds ONE
-            // element of -Q_xu and of K^T per step instead of all lanes reading all of K^T by broadcast (66 ds_read_b64 per
-            // lane against 342 ds_read_b128).  Nine independent accumulators, k outermost, keep the pipe fed.
-            {
-                const int li = lane & 15, lk = lane >> 4;
-                double av[15], bv[15], c0[12], c1[12], c2[12];
-                lds_read_mfma_operand(lds_offset(s.Qs + li * LDK + lk), av);
-                lds_read_mfma_operand(lds_offset(Ks + li * LDK + lk), bv);
-                const unsigned nbase = lds_offset(s.N + lk * LD + li);
-                lds_read_mfma_acc_row<0>(nbase, c0);
-                lds_read_mfma_acc_row<1>(nbase, c1);
-                lds_read_mfma_acc_row<2>(nbase, c2);
-                mfma_acc_t acc[9];
-                UNROLL_RBD for (int J = 0; J < 3; ++J)
-                    UNROLL_RBD for (int v = 0; v < 4; ++v) { acc[J][v] = c0[4 * J + v]; acc[3 + J][v] = c1[4 * J + v]; acc[6 + J][v] = c2[4 * J + v]; }
-                UNROLL_RBD for (int ks = 0; ks < 5; ++ks)
-                    UNROLL_RBD for (int I = 0; I < 3; ++I)
-                        UNROLL_RBD for (int J = 0; J < 3; ++J)
-                            acc[3 * I + J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[5 * I + ks], bv[5 * J + ks], acc[3 * I + J], 0, 0, 0);
-                UNROLL_RBD for (int I = 0; I < 3; ++I)
-                    UNROLL_RBD for (int J = 0; J < 3; ++J)
-                        if (J < 2 || li < kNDX - 32)       // columns 36..47 do not exist (rows 36..47 do, as padding)
-                            UNROLL_RBD for (int v = 0; v < 4; ++v) s.N[(16 * I + lk + 4 * v) * LD + 16 * J + li] = acc[3 * I + J][v];
-            }
+            UNROLL_RBD for (int I = 0; I < 3; ++I)
+                UNROLL_RBD for (int J = I; J < 3; ++J)
+                    if (J < 2 || li < kNDX - 32) {      // columns 36..47 do not exist (rows 36..47 do, as padding)
+                        const int tl = (I == 0 ? 0 : I == 1 ? 2 : 3) + J;
+                        UNROLL_RBD for (int v = 0; v < 4; ++v) {
+                            const int i = 16 * I + lk + 4 * v, j = 16 * J + li;
+                            s.N[i * LD + j] = acc[tl][v];
+                            if (J > I) s.N[j * LD + i] = acc[tl][v];
+                        }
+                    }
             __syncthreads();
             PSTAMPV(7, vx)
             // V = (V_xx + V_xx^T)/2 + xreg I: own row and own column of the staged V_xx (xreg added to the staged diagonal)
