@@ -181,7 +181,7 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run) {
     int active = a.B, it = 0;
     while (it < a.maxiter && active > 0) {
         const int chunk = active <= g_spec_line_search_below ? kTailChunk : 1;
-        a.fwd_spec = active <= g_spec_line_search_below ? 1 : 0;
+        a.fwd_spec = active <= g_spec_line_search_below / 3 ? 3 : active <= g_spec_line_search_below ? 2 : 0;
         for (int k = 0; k < chunk && it < a.maxiter; ++k, ++it) {
             HIP_TRY(bunmpc::ik_launch_calcdiff(a, st));
             HIP_TRY(bunmpc::ik_launch_backward(a, st));

@@ -769,14 +769,16 @@ struct ForwardLds { RobotModelDev m; FwdSub sub[kFwdSub]; double vote[kFwdSub], 
 //      passing one is the same decision -- it trades idle SIMDs for a 4x shorter serial chain when few problems
 //      are still iterating.
 //
-// NW = 2 (used with the speculative mapping): a second wave takes the cost side of every node (state regularisation
-// residual, leg walks, their sum) while wave 0 runs the chain x -> dx -> u -> Euler step -> next x; the two meet once per
-// node.  Different code cannot overlap inside a wave, but it can across the waves of a workgroup.
+// NW > 1 (used with the speculative mapping): wave 1 takes the leg walks of every node and their sum, the last wave the
+// state regularisation residual (an SE(3) difference, as long as a leg walk; with NW = 2 that is wave 1 again, one after
+// the other), while wave 0 runs the chain x -> dx -> u -> Euler step -> next x; they meet once per node.  Different code
+// cannot overlap inside a wave, but it can across the waves of a workgroup.  Two waves while the problems still cover
+// the chip (<= 1024 active), three once a third of the SIMDs would be idle anyway.
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a) {
     __shared__ ForwardLds s;
-    const int lane = threadIdx.x & 63, wave = NW == 2 ? (int)(threadIdx.x >> 6) : 0, si = lane / kFwdLanes, l = lane % kFwdLanes;
-    const bool do_chain = NW == 1 || wave == 0, do_cost = NW == 1 || wave == 1;
+    const int lane = threadIdx.x & 63, wave = NW > 1 ? (int)(threadIdx.x >> 6) : 0, si = lane / kFwdLanes, l = lane % kFwdLanes;
+    const bool do_chain = NW == 1 || wave == 0, do_cost = NW == 1 || wave == 1, do_reg = NW == 1 || wave == NW - 1;
     const bool spec = a.fwd_spec != 0;
     const long b = spec ? (long)blockIdx.x : (long)blockIdx.x * kFwdSub + si;
     const bool pvalid = b < a.B;
@@ -851,7 +853,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
             }
             // phase 1: dx = xs[t] (-) x on lane 0 (feeds the feedback) and the state regularisation residual x_reg (-) x on
             // lane 5 (feeds the cost) -- one instruction stream when one wave does both
-            const bool want_dx = do_chain && l == 0 && !terminal, want_rs = do_cost && l == 5 && tk.state_w() != 0.0;
+            const bool want_dx = do_chain && l == 0 && !terminal, want_rs = do_reg && l == 5 && tk.state_w() != 0.0;
             if (run && (want_dx || want_rs)) {
                 double d[kNDX];
                 state_diff<false>(want_dx ? q.xs : x_reg, q.x, d, nullptr);
@@ -861,7 +863,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
                     UNROLL_RBD for (int i = 0; i < kNDX; ++i) acc += state_w[i] * d[i] * d[i];
                     q.bc[2] = tk.state_w() * 0.5 * acc;
                 }
-            } else if (run && do_cost && l == 5) q.bc[2] = 0.0;
+            } else if (run && do_reg && l == 5) q.bc[2] = 0.0;
             // phase 2 (needs x only): legs on lanes 0..3, base body on lane 4
             if (run && do_cost && l <= kLegs) {
                 int fid[kFrameSlots];
@@ -874,7 +876,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
                 UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
                     UNROLL_RBD for (int c = 0; c < 3; ++c) q.part[l][10 + 3 * f + c] = ps.fhit[f] ? ps.fx[f][c] : 0.0;
             }
-            if (NW == 1) __syncthreads();   // with two waves each side hands over inside its own wave (LDS keeps a wave's order)
+            if (NW == 1) __syncthreads();   // with several waves each side hands over inside its own wave (LDS keeps a wave's order)
             // phase 3: feedback u = u - alpha k - K dx, two rows per lane (0..8 own rows l and l + 9), rows fetched a node ahead
             if (run && do_chain && !terminal && l < 9) {
                 double v0 = up0 - al * fp0, v1 = up1 - al * fp1;
@@ -1072,7 +1074,8 @@ hipError_t ik_launch_backward(const IkBatchArgs &a, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t ik_launch_forward(const IkBatchArgs &a, hipStream_t st) {
-    if (a.fwd_spec) hipLaunchKernelGGL(ik_forward_kernel<2>, dim3(a.B), dim3(128), 0, st, a);
+    if (a.fwd_spec == 3) hipLaunchKernelGGL(ik_forward_kernel<3>, dim3(a.B), dim3(192), 0, st, a);
+    else if (a.fwd_spec) hipLaunchKernelGGL(ik_forward_kernel<2>, dim3(a.B), dim3(128), 0, st, a);
     else hipLaunchKernelGGL(ik_forward_kernel<1>, dim3((a.B + 3) / 4), dim3(64), 0, st, a);
     return hipGetLastError();
 }

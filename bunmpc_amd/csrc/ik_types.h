@@ -68,7 +68,8 @@ enum IkScal { S_COST = 0, S_XREG, S_D1, S_D2, S_STOP, S_FEAS, S_WASFEAS, S_DONE,
 
 struct IkBatchArgs {
     int B, T, maxiter;
-    int fwd_spec;              // forward pass: 1 = one problem per wave, four step lengths at once (few active problems)
+    int fwd_spec;              // forward pass: 0 = four problems per wave; 2 / 3 = one problem per workgroup of 2 / 3 waves,
+                               // four step lengths at once (few active problems)
     const RobotModelDev *model;
     const double *x0;          // [B][37]
     const double *dt;          // [B][T]
