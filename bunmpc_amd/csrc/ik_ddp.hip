@@ -814,6 +814,9 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
     bool accepted = false;
     int win = 0;                        // trial slot holding the accepted trajectory
     double alpha = 1.0, cost_try = 0.0;
+#ifdef BWD_PROFILE
+    long long fwork = 0, fwait = 0;
+#endif
     for (int round = 0; round < 10; ++round) {   // alphas_ = 2^-n, n = 0..9
         if (!__any(live)) break;
         const int ia = spec ? kFwdSub * round + si : round;
@@ -837,6 +840,9 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
         __syncthreads();
         for (int t = 0; t <= T; ++t) {   // t == T: terminal node (cost only)
             if (!__any(run)) break;
+#ifdef BWD_PROFILE
+            const long long fnode0 = __builtin_readcyclecounter();
+#endif
             const bool terminal = t == T;
             NodeTasks tk{q.tk};
             const double dtn = terminal ? 0.0 : q.tk[kNodeTaskDoubles];
@@ -935,7 +941,13 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
                 }
                 q.bc[0] = c;
             }
+#ifdef BWD_PROFILE
+            { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); fwork += __builtin_readcyclecounter() - fnode0; }
+#endif
             __syncthreads();
+#ifdef BWD_PROFILE
+            fwait += __builtin_readcyclecounter() - fnode0;
+#endif
             if (run) {
                 double c = q.bc[0] + (q.bc[2] + q.bc[3]);     // node cost: residual terms + (state + control)
                 if (!terminal) c *= dtn;
@@ -974,6 +986,9 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
             __syncthreads();
         }
     }
+#ifdef BWD_PROFILE
+    if (pvalid && lane == 0) { ws[L.Qu + 8 + 2 * wave] = (double)fwork; ws[L.Qu + 9 + 2 * wave] = (double)fwait; }   // tools/bwd_profile.py
+#endif
     if (!owner || !do_chain) return;
     double xreg = sc[S_XREG];
     if (accepted) {   // setCandidate(xs_try, us_try, true)

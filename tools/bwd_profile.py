@@ -18,5 +18,7 @@ for B in (1, 4096):
     names = "stage apply1 row+apply2 qxu+Lxx chol solve store+vx schur sym+fs".split()
     oq = o - T * 18
     cd = ws[:, oq:oq + 4].mean(0)
+    fw = ws[:, oq + 8:oq + 14].mean(0)
+    print("B", B, "forward (last call) cycles to the node barrier / incl. barrier, summed over nodes and rounds: chain %d / %d, legs %d / %d, reg %d / %d" % tuple(fw))
     print("B", B, "calcdiff node 0 cycles: stage %d, walk || state+Euler %d, totals+columns %d, assembly %d" % tuple(cd))
     print("B", B, "cycles/node:", " ".join("%s %d" % (n, v) for n, v in zip(names, c.mean(0))), "| sum", round(c.mean(0).sum()))
