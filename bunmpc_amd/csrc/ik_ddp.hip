@@ -408,6 +408,7 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a
 // transposition later it holds row r of N and finishes row r of G = N F_x, again lane-locally.
 constexpr int LD = kNDX + 1;   // odd leading dimension: rows and columns of 64-bit words are both conflict-free
 constexpr int LDU = kNV + 1;
+constexpr int kQuLane = kNDX + kNV;   // backward pass: lanes 0..35 x-rows, 36..53 rows of Q_uu, 54 the Q_u row
 // The Schur update V_xx = Q_xx - Q_xu K = Q_xx - Y^T Y (Y = L^-1 Q_ux) runs on the matrix pipe as tiles of v_mfma_f64_16x16x4
 // (36 -> 48, k: 18 -> 20).  Operand image in LDS: Y^T as [48][LDK] (zero outside 36 x 18, so the padding contributes nothing),
 // Q_xx / V_xx in the rows of N ([48][LD]: the padded rows are read and written but never used).  Lane l holds A[l & 15][k = l >> 4],
@@ -465,8 +466,8 @@ __device__ __forceinline__ double rcp64(double b) {
 struct alignas(16) BackwardLds {
     double N[kPadRows * LD + 16];   // row-major staging: N = F_x^T V for the transposition, later Q_xx -> V_xx rows
     double Ys[kPadRows * LDK];      // Y^T, Y = L^-1 Q_ux (36 x 18 in a zeroed 48 x 21 image): both operands of the Schur update
-    double Lr[5 * 36], Lc[5 * 36];   // Cholesky factor packed by rows (L[p][q], q < p, at p(p-1)/2 + q) and by columns
-                                     // (L[q][p], q > p, at p(35-p)/2 + q-p-1), read back by broadcast in batches of 36
+    double Lc[5 * 36];              // Cholesky factor packed by columns (L[q][p], q > p, at p(35-p)/2 + q-p-1), read back by
+                                    // broadcast in batches of 36
     double A6[36], B6[36];
     double Vx[kNDX], fs[kNDX];
 };
@@ -529,7 +530,9 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
     }
 
     const bool row = lane < kNDX;                  // owns row `lane` of the 36x36 matrices
-    const int r = row ? lane : 0;
+    // lanes 36..53 shadow lanes 18..35 (same reads, same arithmetic, no writes): their copy of rows 18..35 of G becomes the
+    // rows of Q_uu in the elimination, where lanes 18..35 themselves carry rows of Q_xu
+    const int r = row ? lane : (lane < kNDX + kNV ? lane - kNV : 0);
     const bool ul = lane >= kNV && lane < kNDX;    // owns control q = lane - 18 (rows 18..35 are the v-rows)
     const int uq = ul ? lane - kNV : 0;
     const unsigned row_addr = lds_offset(s.N + r * LD), col_addr = lds_offset(s.N + r);
@@ -566,7 +569,8 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             // every global read of this node is issued here, so that the L_xx row (36 doubles per lane) travels while the
             // F_x^T products and the transposition run
             const double lx_t = row ? ws[L.Lx + (long)t * kNDX + r] : 0.0;
-            const double lu_t = ul ? ws[L.Lu + (long)t * kNV + uq] : 0.0, luu_t = ul ? ws[L.Luu + (long)t * kNV + uq] : 0.0;
+            const double lu_t = ul ? ws[L.Lu + (long)t * kNV + uq] : 0.0;
+            const double luu_t = lane >= kNDX && lane < kNDX + kNV ? ws[L.Luu + (long)t * kNV + lane - kNDX] : 0.0;   // on the lane of Q_uu row p
             double lr[kNDX];
             {
                 const double *Lr = ws + L.Lxx + (long)t * kNDX * kNDX + (long)r * kNDX;
@@ -591,52 +595,44 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             else fvx = dt * s.Vx[r - kNV] + s.Vx[r];
             const double qx = lx_t + fvx;
             const double qu = ul ? lu_t + dt * fvx : 0.0;   // Q_u[q] on lane 18 + q
-            // Q_xu row; Q_uu row p on lane 18 + p (without its L_uu + reg diagonal term, kept in dgv); Q_xx row -> LDS
-            double qxu[kNV], al[kNV];
-            UNROLL_RBD for (int q = 0; q < kNV; ++q) { qxu[q] = dt * m[kNV + q]; al[q] = dt * qxu[q]; }
-            const double dgv = ul ? luu_t + xreg : 0.0;
-            if (row) { UNROLL_RBD for (int j = 0; j < kNDX; ++j) s.N[r * LD + j] = m[j] + lr[j]; }
+            // The factorisation and the forward substitutions in one elimination.  Y^T = Q_xu L^-T obeys the recurrence of the
+            // rows of L itself:  Y^T[r][j] = (Q_xu[r][j] - sum_{k<j} Y^T[r][k] L[j][k]) / L[j][j],  so the rows of Q_xu ride along
+            // as extra rows of the matrix being factorised -- [Q_xu (lanes 0..35); Q_uu (lanes 36..53); Q_u^T (lane 54)], one row
+            // per lane, the same instructions for all of them: the right-looking Cholesky loop of Q_uu leaves L on the u-lanes,
+            // Y^T on the x-lanes and y_u = L^-1 Q_u on lane 54, and the 37 forward substitutions cost nothing beyond it.
+            // Q_uu row p = dt Q_xu[18 + p][:] is at hand on lane 36 + p, which shadows lane 18 + p.
+            double al[kNV], quv[kNV];
+            const bool urow = lane >= kNDX && lane < kQuLane;
+            UNROLL_RBD for (int q = 0; q < kNV; ++q) {
+                const double xq = dt * m[kNV + q];                       // Q_xu[r][q]
+                quv[q] = lane_value(qu, kNV + q);
+                al[q] = urow ? dt * xq : (lane == kQuLane ? quv[q] : xq);   // Q_uu[p][q] without its diagonal term / Q_u / Q_xu
+            }
+            const double dgv = urow ? luu_t + xreg : 0.0;                // L_uu + reg of control p on lane 36 + p
+            if (row) { UNROLL_RBD for (int j = 0; j < kNDX; ++j) s.N[r * LD + j] = m[j] + lr[j]; }       // Q_xx row -> LDS
             PSTAMPV(3, al[17])
-            // Cholesky Q_uu = L L^T entirely in registers: lane 18 + p owns row p, the column entries and pivots
-            // every lane needs travel by v_readlane (wave-uniform, no LDS, no waiting).  A non-positive or NaN
-            // pivot fails the pass (Eigen::LLT info != Success).
+            // Pivots and the column entries every lane needs travel by v_readlane (wave-uniform, no LDS, no waiting).  A
+            // non-positive or NaN pivot fails the pass (Eigen::LLT info != Success).
             double idg[kNV];
             UNROLL_RBD for (int j = 0; j < kNV; ++j) {
-                const double piv = lane_value(al[j], kNV + j) + lane_value(dgv, kNV + j);
+                const double piv = lane_value(al[j], kNDX + j) + lane_value(dgv, kNDX + j);
                 if (!(piv > 0.0)) bad = true;
                 const double f = al[j] * rcp64(piv);
-                UNROLL_RBD for (int q = j + 1; q < kNV; ++q) al[q] -= f * lane_value(al[j], kNV + q);
+                UNROLL_RBD for (int q = j + 1; q < kNV; ++q) al[q] -= f * lane_value(al[j], kNDX + q);
                 idg[j] = rcp64(sqrt(piv));
-                al[j] *= idg[j];                        // L[p][j] for the rows p > j
+                al[j] *= idg[j];                        // L[p][j] (rows p > j) / Y^T[r][j] / y_u[j]
             }
             PSTAMPV(4, idg[17])
-            // The factor goes to LDS once (u-lanes own its rows): the 37 triangular solves then read it back by broadcast
-            // -- one ds_read_b128 per two entries instead of four v_readlane.
-            if (ul) {
-                const int p = uq;
+            // The factor goes to LDS once (packed by columns): the back substitutions read it back by broadcast -- one
+            // ds_read_b128 per two entries instead of four v_readlane.
+            if (urow) {
+                const int p = lane - kNDX;
                 UNROLL_RBD for (int q = 0; q < kNV - 1; ++q) {
-                    if (q < p) { s.Lr[p * (p - 1) / 2 + q] = al[q]; s.Lc[q * (35 - q) / 2 + (p - q - 1)] = al[q]; }
+                    if (q < p) s.Lc[q * (35 - q) / 2 + (p - q - 1)] = al[q];
                 }
             }
-            __syncthreads();
-            // K = Quu^-1 Qxu^T: lane j < 36 solves for column j (18 unknowns in registers); lane 36: k = Quu^-1 Qu
-            double y[kNV], quv[kNV];
-            UNROLL_RBD for (int p = 0; p < kNV; ++p) quv[p] = lane_value(qu, kNV + p);
-            {
-                const unsigned lr_addr = lds_offset(s.Lr);
-                double2_t lb[18];
-                int cur = -1;
-                UNROLL_RBD for (int p = 0; p < kNV; ++p) {
-                    double w = lane < kNDX ? qxu[p] : quv[p];
-                    UNROLL_RBD for (int q = 0; q < p; ++q) {
-                        const int idx = p * (p - 1) / 2 + q, bb = idx / 36, e = idx % 36;
-                        if (bb != cur) { lds_read_b128x18(lr_addr + (unsigned)bb * 288, lb); cur = bb; }
-                        w -= ((e & 1) ? lb[e >> 1].y : lb[e >> 1].x) * y[q];
-                    }
-                    y[p] = w * idg[p];
-                }
-            }
-            // expectedImprovement / stoppingCriteria ingredients (lane 36): d2 = -k.Quu k = -|L^T k|^2 = -|L^-1 Qu|^2
+            double (&y)[kNV] = al;
+            // expectedImprovement / stoppingCriteria ingredients (lane 54): d2 = -k.Quu k = -|L^T k|^2 = -|L^-1 Qu|^2
             UNROLL_RBD for (int p = 0; p < kNV; ++p) d2 -= y[p] * y[p];
             // Y = L^-1 Q_ux (column j on lane j) is all the Riccati recursion needs: Q_xu K = Q_xu Q_uu^-1 Q_ux = Y^T Y.  It goes to
             // LDS as the one operand image of the Schur update; the gains K = L^-T Y (back substitution) are for the forward pass,
@@ -685,7 +681,7 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             if (row) {      // (the empty asm keeps the stores in program order: clustered, hipcc spills a hundred registers around them)
                 double *Kg = ws + L.K + (long)t * kNV * kNDX + r;
                 UNROLL_RBD for (int p = 0; p < kNV; ++p) { Kg[p * kNDX] = y[p]; asm volatile("" ::: "memory"); }
-            } else if (lane == kNDX) {
+            } else if (lane == kQuLane) {
                 UNROLL_RBD for (int p = 0; p < kNV; ++p) ws[L.kff + (long)t * kNV + p] = y[p];
             }
             // V_x = Q_x - K^T Q_u
@@ -743,7 +739,7 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
 #ifdef BWD_PROFILE
     if (lane == 0) { for (int k = 0; k < 9; ++k) ws[L.Quuk + k] = (double)pc[k]; }   // the Quuk slot is unused by the solver
 #endif
-    if (lane == kNDX) { sc[S_D1] = d1; sc[S_D2] = d2; sc[S_STOP] = st; }   // lane 36 solved for the feed-forward terms
+    if (lane == kQuLane) { sc[S_D1] = d1; sc[S_D2] = d2; sc[S_STOP] = st; }   // the lane of the feed-forward terms
 }
 
 // ---------------------------------------------------------------------------- forward ---
