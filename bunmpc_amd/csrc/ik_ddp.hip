@@ -142,6 +142,22 @@ __global__ void ik_init_kernel(const IkBatchArgs a) {
 constexpr int kRes = 6 + 3 + 3 * kFrameSlots;   // 21 residual rows
 constexpr int kResLd = kRes + 1;                // 22 doubles = 11 x 16 bytes per column
 
+typedef double mfma_acc_t __attribute__((ext_vector_type(4)));
+#define CALC_STR2(x) #x
+#define CALC_STR(x) CALC_STR2(x)
+#define CALC_RD(n, I, ks) "ds_read_b64 %" #n ", %18 offset:" CALC_STR(((16 * I * 22 + 4 * ks) * 8)) "\n"
+// o[6 I + ks] = Jt[16 I + (l & 15)][4 ks + (l >> 4)] (rows of kResLd = 22 doubles): the MFMA operand elements of a lane
+__device__ __forceinline__ void lds_read_calc_operand(unsigned base, double (&o)[18]) {
+    static_assert(kResLd == 22, "offsets below are written for rows of 22 doubles");
+    asm volatile(CALC_RD(0, 0, 0) CALC_RD(1, 0, 1) CALC_RD(2, 0, 2) CALC_RD(3, 0, 3) CALC_RD(4, 0, 4) CALC_RD(5, 0, 5)
+                 CALC_RD(6, 1, 0) CALC_RD(7, 1, 1) CALC_RD(8, 1, 2) CALC_RD(9, 1, 3) CALC_RD(10, 1, 4) CALC_RD(11, 1, 5)
+                 CALC_RD(12, 2, 0) CALC_RD(13, 2, 1) CALC_RD(14, 2, 2) CALC_RD(15, 2, 3) CALC_RD(16, 2, 4) CALC_RD(17, 2, 5)
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8]),
+                   "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15]), "=&v"(o[16]), "=&v"(o[17])
+                 : "v"(base) : "memory");
+}
+
 constexpr int kParts = kLegs + 1;        // legs 0..3, base body 4
 constexpr int kPartDoubles = 16;         // Comp (m, h1[3], I[6]) + momentum about the origin (6)
 
@@ -321,74 +337,74 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a
     }
     // node costs are summed by the backward kernel: parked in the fs slot of this node
     if (lane == 63) ws[L.fs + (long)t * kNDX] = terminal ? q.cost_kin + q.cost_sc : dt * (q.cost_kin + q.cost_sc);
-    if (lane >= kNDX) return;
-    // Gauss-Newton L_x / L_xx, lane j = column j:  L_xx[i][j] = sum_k J[k][i] w_k J[k][j]  (+ the state regularisation
-    // block), the weighted own column in registers, row i's column read back by broadcast (ds_read_b128 batches),
-    // stores coalesced across j.
-    const int j = lane;
-    double jw[kRes];
-    {
-        double2_t own[11];
-        lds_read_b128x11(lds_offset(q.Jt[j]), own);
-        UNROLL_RBD for (int k = 0; k < kRes; ++k) jw[k] = (k & 1) ? own[k >> 1].y : own[k >> 1].x;
-    }
-    UNROLL_RBD for (int k = 0; k < 6; ++k) jw[k] *= wm;
-    UNROLL_RBD for (int k = 0; k < 3; ++k) jw[6 + k] *= wc;
-    UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
-        UNROLL_RBD for (int k = 0; k < 3; ++k) jw[9 + 3 * f + k] *= tk.frame_w(f);
-    const double swj = wst * state_w[j];
-    double jlw[6];     // wst * state_w[k] * Jl[k][j] for the 6x6 free-flyer block of the state residual Jacobian
-    UNROLL_RBD for (int k = 0; k < 6; ++k) jlw[k] = j < 6 ? wst * state_w[k] * q.JlT[j][k] : 0.0;
-    {   // L_x
+    // Gauss-Newton L_x (lane j = entry j): the weighted own column of the residual Jacobian against the residuals.
+    const int j = lane < kNDX ? lane : 0;
+    if (lane < kNDX) {
+        double jw[kRes];
+        {
+            double2_t own[11];
+            lds_read_b128x11(lds_offset(q.Jt[j]), own);
+            UNROLL_RBD for (int k = 0; k < kRes; ++k) jw[k] = (k & 1) ? own[k >> 1].y : own[k >> 1].x;
+        }
+        UNROLL_RBD for (int k = 0; k < 6; ++k) jw[k] *= wm;
+        UNROLL_RBD for (int k = 0; k < 3; ++k) jw[6 + k] *= wc;
+        UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
+            UNROLL_RBD for (int k = 0; k < 3; ++k) jw[9 + 3 * f + k] *= tk.frame_w(f);
         double2_t rr[11];
         lds_read_b128x11(lds_offset(q.res), rr);
         double g = 0.0;
         UNROLL_RBD for (int k = 0; k < kRes; ++k) g += jw[k] * ((k & 1) ? rr[k >> 1].y : rr[k >> 1].x);
-        if (j < 6) { UNROLL_RBD for (int k = 0; k < 6; ++k) g += jlw[k] * q.rs[k]; }
-        else g += swj * q.rs[j];
+        if (j < 6) { UNROLL_RBD for (int k = 0; k < 6; ++k) g += wst * state_w[k] * q.JlT[j][k] * q.rs[k]; }
+        else g += wst * state_w[j] * q.rs[j];
         ws[L.Lx + (long)t * kNDX + j] = sc * g;
     }
-    double *Lxx = ws + L.Lxx + (long)t * kNDX * kNDX;
-    const unsigned jt_addr = lds_offset(q.Jt), jl_addr = lds_offset(q.JlT);
-    for (int i0 = 0; i0 < 6; i0 += 2) {    // rows of the free-flyer block: all 21 residual rows + the Jlog6 block
-        double2_t ri[22], jl[3], jl2[3];
-        lds_read_b128x22(jt_addr + (unsigned)i0 * (kResLd * 8), ri);
-        lds_read_b128x3(jl_addr + (unsigned)i0 * 48, jl);
-        lds_read_b128x3(jl_addr + (unsigned)(i0 + 1) * 48, jl2);
-        double h0 = 0.0, h1 = 0.0;
-        UNROLL_RBD for (int k = 0; k < kRes; ++k) {
-            h0 += jw[k] * ((k & 1) ? ri[k >> 1].y : ri[k >> 1].x);
-            h1 += jw[k] * ((k & 1) ? ri[11 + (k >> 1)].y : ri[11 + (k >> 1)].x);
+    // Gauss-Newton L_xx = J^T W J (+ the state regularisation: its Jlog6 block on the free-flyer, its weights on the rest of
+    // the diagonal) on the matrix pipe: 3 x 3 tiles of v_mfma_f64_16x16x4 over the 21 residual rows (24 with padding), the
+    // rows of Jt in LDS serving as both operands (A weighted).  Lane l holds A[l & 15][k = l >> 4], B[k][l & 15] and
+    // D[(l >> 4) + 4 v][l & 15]; as in the Riccati pass' Schur update this is about instruction count and LDS traffic
+    // (every lane read two rows of Jt by broadcast per two output rows before), not about flops.
+    {
+        const int li = lane & 15, lk = lane >> 4;
+        double av[18], bv[18];      // [6 I + ks]: Jt[16 I + li][4 ks + lk]
+        lds_read_calc_operand(lds_offset(&q.Jt[0][0]) + (unsigned)(li * kResLd + lk) * 8u, bv);
+        UNROLL_RBD for (int ks = 0; ks < 6; ++ks) {
+            const int k = 4 * ks + lk;                       // residual row this lane feeds in k-step ks
+            const int f = k >= 9 ? (k - 9) / 3 : 0;
+            const double fw = f == 0 ? tk.frame_w(0) : f == 1 ? tk.frame_w(1) : f == 2 ? tk.frame_w(2) : tk.frame_w(3);
+            const double w = k < 6 ? wm : k < 9 ? wc : k < kRes ? fw : 0.0;
+            UNROLL_RBD for (int I = 0; I < 3; ++I) {
+                if (ks == 5) bv[6 * I + ks] = k < kRes ? bv[6 * I + ks] : 0.0;     // columns 21..23 are padding / the next row
+                av[6 * I + ks] = w * bv[6 * I + ks];
+            }
         }
-        UNROLL_RBD for (int k = 0; k < 6; ++k) {
-            h0 += jlw[k] * ((k & 1) ? jl[k >> 1].y : jl[k >> 1].x);
-            h1 += jlw[k] * ((k & 1) ? jl2[k >> 1].y : jl2[k >> 1].x);
+        double *Lxx = ws + L.Lxx + (long)t * kNDX * kNDX;
+        double swj[3];
+        UNROLL_RBD for (int J = 0; J < 3; ++J) { const int jj = 16 * J + li; swj[J] = jj >= 6 && jj < kNDX ? wst * state_w[jj] : 0.0; }
+        UNROLL_RBD for (int I = 0; I < 3; ++I) {             // one block row of tiles at a time: three accumulators live
+            mfma_acc_t acc[3];
+            UNROLL_RBD for (int J = 0; J < 3; ++J) acc[J] = mfma_acc_t{0.0, 0.0, 0.0, 0.0};
+            UNROLL_RBD for (int ks = 0; ks < 6; ++ks)
+                UNROLL_RBD for (int J = 0; J < 3; ++J)
+                    if (ks < 2 || (I < 2 && J < 2))        // rows / columns 32..35 are velocity columns of J: only the momentum rows k < 6
+                        acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[6 * I + ks], bv[6 * J + ks], acc[J], 0, 0, 0);
+            if (I == 0) {
+                UNROLL_RBD for (int ks = 0; ks < 2; ++ks) {  // the Jlog6 block: rows / columns 0..5 of tile (0, 0)
+                    const int k = 4 * ks + lk;
+                    const bool ok = li < 6 && k < 6;
+                    const double jl = q.JlT[ok ? li : 0][ok ? k : 0], swk = state_w[ok ? k : 0];
+                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? wst * swk * jl : 0.0, ok ? jl : 0.0, acc[0], 0, 0, 0);
+                }
+            }
+            UNROLL_RBD for (int J = 0; J < 3; ++J) {
+                const int jj = 16 * J + li;
+                if (jj < kNDX) {
+                    UNROLL_RBD for (int v = 0; v < 4; ++v) {
+                        const int i = 16 * I + lk + 4 * v;
+                        if (i < kNDX) Lxx[(long)i * kNDX + jj] = sc * (acc[J][v] + (i == jj ? swj[J] : 0.0));
+                    }
+                }
+            }
         }
-        Lxx[(long)i0 * kNDX + j] = sc * h0;
-        Lxx[(long)(i0 + 1) * kNDX + j] = sc * h1;
-    }
-    for (int i0 = 6; i0 < kNV; i0 += 2) {   // joint rows
-        double2_t ri[22];
-        lds_read_b128x22(jt_addr + (unsigned)i0 * (kResLd * 8), ri);
-        double h0 = 0.0, h1 = 0.0;
-        UNROLL_RBD for (int k = 0; k < kRes; ++k) {
-            h0 += jw[k] * ((k & 1) ? ri[k >> 1].y : ri[k >> 1].x);
-            h1 += jw[k] * ((k & 1) ? ri[11 + (k >> 1)].y : ri[11 + (k >> 1)].x);
-        }
-        Lxx[(long)i0 * kNDX + j] = sc * (h0 + (i0 == j ? swj : 0.0));
-        Lxx[(long)(i0 + 1) * kNDX + j] = sc * (h1 + (i0 + 1 == j ? swj : 0.0));
-    }
-    for (int i0 = kNV; i0 < kNDX; i0 += 2) {      // velocity rows: only the 6 momentum rows are non-zero
-        double2_t ra[3], rb[3];
-        lds_read_b128x3(jt_addr + (unsigned)i0 * (kResLd * 8), ra);
-        lds_read_b128x3(jt_addr + (unsigned)(i0 + 1) * (kResLd * 8), rb);
-        double h0 = 0.0, h1 = 0.0;
-        UNROLL_RBD for (int k = 0; k < 6; ++k) {
-            h0 += jw[k] * ((k & 1) ? ra[k >> 1].y : ra[k >> 1].x);
-            h1 += jw[k] * ((k & 1) ? rb[k >> 1].y : rb[k >> 1].x);
-        }
-        Lxx[(long)i0 * kNDX + j] = sc * (h0 + (i0 == j ? swj : 0.0));
-        Lxx[(long)(i0 + 1) * kNDX + j] = sc * (h1 + (i0 + 1 == j ? swj : 0.0));
     }
 #ifdef BWD_PROFILE
     PSTAMP(3)
@@ -416,7 +432,6 @@ constexpr int kQuLane = kNDX + kNV;   // backward pass: lanes 0..35 x-rows, 36..
 // from one per-lane base address, so the reads are batches of ds_read_b64 with immediate offsets (lds_batch.h explains
 // why they are asm: hipcc puts a full wait after each LDS read it schedules itself).
 constexpr int LDK = 21, kPadRows = 48;
-typedef double mfma_acc_t __attribute__((ext_vector_type(4)));
 #define BWD_STR2(x) #x
 #define BWD_STR(x) BWD_STR2(x)
 #define BWD_OFFK(I, ks) ((16 * I * 21 + 4 * ks) * 8)
