@@ -257,6 +257,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-kinodyn", action="store_true")
+    ap.add_argument("--kinodyn-main-only", action="store_true", help="skip the Go2 H=60 and data-path legs (counter collection)")
     ap.add_argument("--kinodyn-streams", type=int, default=3, help="batches in flight in the multi-stream KinoDyn measurement")
     ap.add_argument("--kinodyn-batch", type=int, default=4096)
     ap.add_argument("--kinodyn-config", default="solo12_h20", choices=["solo12_h20", "go2_h60"],
@@ -363,7 +364,7 @@ def main():
             out["host_buffers_solves_per_s"] = 3 * B / (time.perf_counter() - th)
         if world == 1 and not args.no_kinodyn:
             out["kinodyn_full_solve"] = kinodyn_leg(dev, args.kinodyn_batch, args.admm_iters, args.maxit, args.kinodyn_config, n_streams=args.kinodyn_streams)
-            if args.kinodyn_config == "solo12_h20":   # BASELINE config 5's shape as well (1024 problems = its per-GPU share)
+            if args.kinodyn_config == "solo12_h20" and not args.kinodyn_main_only:   # BASELINE config 5's shape as well (1024 problems = its per-GPU share)
                 out["kinodyn_go2_h60"] = kinodyn_leg(dev, 1024, args.admm_iters, args.maxit, "go2_h60", n_streams=args.kinodyn_streams)
                 out["datagen_pass"] = datagen_leg(dev, args.kinodyn_batch, args.admm_iters)
         print(json.dumps(out))

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" \
            "SQ_WAVES SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY"; do
   tag=$(echo $set | md5sum | cut -c1-6)
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d ${out}_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --batch 64 --no-cpu --no-latency --kinodyn-batch $kb > ${out}_$tag.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d ${out}_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --batch 64 --no-cpu --no-latency --kinodyn-main-only --kinodyn-streams 1 --kinodyn-batch $kb > ${out}_$tag.log 2>&1
   python3 - <<PY
 import csv, glob, collections
 f = glob.glob("${out}_$tag/*/*counter_collection.csv")[0]
