@@ -780,16 +780,17 @@ struct ForwardLds { RobotModelDev m; FwdSub sub[kFwdSub]; double vote[kFwdSub], 
 //      passing one is the same decision -- it trades idle SIMDs for a 4x shorter serial chain when few problems
 //      are still iterating.
 //
-// NW > 1 (used with the speculative mapping): wave 1 takes the leg walks of every node and their sum, the last wave the
-// state regularisation residual (an SE(3) difference, as long as a leg walk; with NW = 2 that is wave 1 again, one after
-// the other), while wave 0 runs the chain x -> dx -> u -> Euler step -> next x; they meet once per node.  Different code
+// NW > 1 (used with the speculative mapping): wave 1 takes the leg walks of every node and their sum, wave 2 the state
+// regularisation residual (an SE(3) difference, as long as a leg walk; with NW = 2 it stays on wave 0, where it is the
+// SAME code as the chain's dx = xs (-) x with other operands and lane 5 runs it in the instruction stream lane 0 needs
+// anyway), while wave 0 runs the chain x -> dx -> u -> Euler step -> next x; they meet once per node.  Different code
 // cannot overlap inside a wave, but it can across the waves of a workgroup.  Two waves while the problems still cover
 // the chip (<= 1024 active), three once a third of the SIMDs would be idle anyway.
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a) {
     __shared__ ForwardLds s;
     const int lane = threadIdx.x & 63, wave = NW > 1 ? (int)(threadIdx.x >> 6) : 0, si = lane / kFwdLanes, l = lane % kFwdLanes;
-    const bool do_chain = NW == 1 || wave == 0, do_cost = NW == 1 || wave == 1, do_reg = NW == 1 || wave == NW - 1;
+    const bool do_chain = NW == 1 || wave == 0, do_cost = NW == 1 || wave == 1, do_reg = NW == 1 || wave == (NW == 2 ? 0 : 2);
     const bool spec = a.fwd_spec != 0;
     const long b = spec ? (long)blockIdx.x : (long)blockIdx.x * kFwdSub + si;
     const bool pvalid = b < a.B;
