@@ -156,13 +156,17 @@ bunmpc::IkBatchArgs make_args(int B, int T, int maxiter, const bmpc_model *model
 int g_spec_line_search_below = 1024;
 constexpr int kMaxIkCol = 63;     // T + 1 <= 64 nodes: the backward pass computes the gaps one lane per node
 
-// one host-mapped word per host thread, through which the kernels' active counter reaches the DDP loop
+// two host-mapped words and events per host thread, through which the kernels' active counter reaches the DDP loop
 struct ActiveWord {
-    int *host = nullptr, *dev = nullptr;
+    int *host[2] = {nullptr, nullptr}, *dev[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
     int ensure() {
-        if (host) return BMPC_OK;
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&host), sizeof(int), hipHostMallocMapped));
-        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&dev), host, 0));
+        if (host[0]) return BMPC_OK;
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&host[k]), sizeof(int), hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&dev[k]), host[k], 0));
+            HIP_TRY(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+        }
         return BMPC_OK;
     }
 };
@@ -171,15 +175,17 @@ thread_local ActiveWord g_active_word;
 int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run) {
     bunmpc::IkBatchArgs a = a0;
     a.fwd_spec = 0;
-    if (int rc = g_active_word.ensure()) return rc;
+    ActiveWord &w = g_active_word;
+    if (int rc = w.ensure()) return rc;
     HIP_TRY(bunmpc::ik_launch_init(a, st));
     // The host looks at the active counter after every iteration while many problems are iterating (iterations are long
     // there and the line-search mapping depends on it); once few are left it enqueues kTailChunk iterations per look --
-    // kernels of a finished problem return at once, so an iteration too many costs a few microseconds, while every
-    // look costs a drained queue.
+    // kernels of a finished problem return at once, so an iteration too many costs a few microseconds.  And it looks
+    // one chunk late: the next chunk is enqueued BEFORE the host waits for the counter of the one before, so the queue
+    // never drains while the host turns around (at the end one chunk of no-op kernels runs out on its own).
     constexpr int kTailChunk = 3;
     int active = a.B, it = 0;
-    while (it < a.maxiter && active > 0) {
+    auto enqueue_chunk = [&](int slot) -> int {
         const int chunk = active <= g_spec_line_search_below ? kTailChunk : 1;
         a.fwd_spec = active <= g_spec_line_search_below / 3 ? 3 : active <= g_spec_line_search_below ? 2 : 0;
         for (int k = 0; k < chunk && it < a.maxiter; ++k, ++it) {
@@ -187,9 +193,21 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run) {
             HIP_TRY(bunmpc::ik_launch_backward(a, st));
             HIP_TRY(bunmpc::ik_launch_forward(a, st));
         }
-        HIP_TRY(bunmpc::ik_launch_publish_active(a.active, g_active_word.dev, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        active = *static_cast<volatile int *>(g_active_word.host);
+        HIP_TRY(bunmpc::ik_launch_publish_active(a.active, w.dev[slot], st));
+        HIP_TRY(hipEventRecord(w.ev[slot], st));
+        return BMPC_OK;
+    };
+    int slot = 0;
+    if (a.maxiter > 0 && active > 0) {
+        if (int rc = enqueue_chunk(slot)) return rc;
+        for (;;) {
+            const bool more = it < a.maxiter;
+            if (more) { if (int rc = enqueue_chunk(slot ^ 1)) return rc; }
+            HIP_TRY(hipEventSynchronize(w.ev[slot]));
+            active = *static_cast<volatile int *>(w.host[slot]);
+            if (active <= 0 || !more) break;
+            slot ^= 1;
+        }
     }
     if (iters_run) *iters_run = it;
     return BMPC_OK;
