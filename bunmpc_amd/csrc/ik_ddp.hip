@@ -827,7 +827,10 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
     int win = 0;                        // trial slot holding the accepted trajectory
     double alpha = 1.0, cost_try = 0.0;
 #ifdef BWD_PROFILE
-    long long fwork = 0, fwait = 0;
+    long long fwork = 0, fwait = 0, fph[5] = {0, 0, 0, 0, 0}, fpt = 0;
+#define FSTAMP(k) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long now_ = __builtin_readcyclecounter(); fph[k] += now_ - fpt; fpt = now_; }
+#else
+#define FSTAMP(k)
 #endif
     for (int round = 0; round < 10; ++round) {   // alphas_ = 2^-n, n = 0..9
         if (!__any(live)) break;
@@ -854,6 +857,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
             if (!__any(run)) break;
 #ifdef BWD_PROFILE
             const long long fnode0 = __builtin_readcyclecounter();
+            fpt = fnode0;
 #endif
             const bool terminal = t == T;
             NodeTasks tk{q.tk};
@@ -882,6 +886,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
                     q.bc[2] = tk.state_w() * 0.5 * acc;
                 }
             } else if (run && do_reg && l == 5) q.bc[2] = 0.0;
+            FSTAMP(0)
             // phase 2 (needs x only): legs on lanes 0..3, base body on lane 4
             if (run && do_cost && l <= kLegs) {
                 int fid[kFrameSlots];
@@ -894,6 +899,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
                 UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
                     UNROLL_RBD for (int c = 0; c < 3; ++c) q.part[l][10 + 3 * f + c] = ps.fhit[f] ? ps.fx[f][c] : 0.0;
             }
+            FSTAMP(1)
             if (NW == 1) __syncthreads();   // with several waves each side hands over inside its own wave (LDS keeps a wave's order)
             // phase 3: feedback u = u - alpha k - K dx, two rows per lane (0..8 own rows l and l + 9), rows fetched a node ahead
             if (run && do_chain && !terminal && l < 9) {
@@ -908,6 +914,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
                     fp0 = ws[L.kff + (long)(t + 1) * kNV + l]; fp1 = ws[L.kff + (long)(t + 1) * kNV + l + 9];
                 }
             }
+            FSTAMP(2)
             if (NW == 1) __syncthreads();
             // phase 4: control cost + Euler step (lane 6)
             if (run && do_chain && l == 6) {
@@ -922,6 +929,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
                 } else q.bc[1] = 0.0;
                 q.bc[3] = tk.ctrl_w() * 0.5 * acc;
             }
+            FSTAMP(3)
             if (NW == 1) __syncthreads();
             // phase 5: the parts added up: CoM, centroidal momentum, their residual costs (without the state / control terms)
             if (run && do_cost && l == 0) {
@@ -977,6 +985,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
                 if (bad) run = false;       // tryStep threw: this step length is out
             }
             __syncthreads();
+            FSTAMP(4)
         }
         bool pass = false;               // the trial ran to the end and passes SolverDDP's acceptance test
         if (live && run) {
@@ -1000,6 +1009,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
     }
 #ifdef BWD_PROFILE
     if (pvalid && lane == 0) { ws[L.Qu + 8 + 2 * wave] = (double)fwork; ws[L.Qu + 9 + 2 * wave] = (double)fwait; }   // tools/bwd_profile.py
+    if (pvalid && lane == 0 && wave == 0) { for (int k = 0; k < 5; ++k) ws[L.Qu + 16 + k] = (double)fph[k]; }
 #endif
     if (!owner || !do_chain) return;
     double xreg = sc[S_XREG];
