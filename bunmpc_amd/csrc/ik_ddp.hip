@@ -765,12 +765,30 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
 constexpr int kFwdSub = 4, kFwdLanes = 64 / kFwdSub;
 static_assert(kFwdSub == kTrySlots, "one trial slot per sub-group");
 
-struct FwdSub {
-    double dx[kNDX], u[kNV], x[kNX], xn[kNX]; double part[kLegs + 1][10 + 3 * kFrameSlots]; double bc[4];
+// Every vector a lane reads as a whole is 16-byte aligned and padded to the length of the batch reader that fetches it
+// (lds_batch.h): read element by element, each LDS read waits out its own latency in front of its first use.
+struct alignas(16) FwdSub {
+    double dx[kNDX], u[22], x[40], xn[40]; double part[kLegs + 1][10 + 3 * kFrameSlots]; double bc[4];
     // copies of what every node reads from HBM: per problem (regularisation reference and weights), per node (task block,
     // dt, the nominal state the feedback is taken around) -- the per-node ones are fetched one node ahead
-    double xreg[kNX], sw[kNDX], cw[kNV], tk[kNodeTaskDoubles + 1], xs[kNX];
+    double xreg[40], sw[kNDX], cw[22], tk[kNodeTaskDoubles + 3], xs[40];
 };
+static_assert((10 + 3 * kFrameSlots) % 2 == 0 && kNodeTaskDoubles % 2 == 1, "FwdSub members stay 16-byte aligned");
+__device__ __forceinline__ void lds_read_vec40(const double *p, double (&o)[40]) {
+    double2_t t[20];
+    lds_read_b128x20(lds_offset(p), t);
+    UNROLL_RBD for (int i = 0; i < 20; ++i) { o[2 * i] = t[i].x; o[2 * i + 1] = t[i].y; }
+}
+__device__ __forceinline__ void lds_read_vec36(const double *p, double (&o)[36]) {
+    double2_t t[18];
+    lds_read_b128x18(lds_offset(p), t);
+    UNROLL_RBD for (int i = 0; i < 18; ++i) { o[2 * i] = t[i].x; o[2 * i + 1] = t[i].y; }
+}
+__device__ __forceinline__ void lds_read_vec22(const double *p, double (&o)[22]) {
+    double2_t t[11];
+    lds_read_b128x11(lds_offset(p), t);
+    UNROLL_RBD for (int i = 0; i < 11; ++i) { o[2 * i] = t[i].x; o[2 * i + 1] = t[i].y; }
+}
 struct ForwardLds { RobotModelDev m; FwdSub sub[kFwdSub]; double vote[kFwdSub], ctry[kFwdSub]; };
 
 // Two mappings of the four sub-groups of a wave (a.fwd_spec, chosen by the host per DDP iteration):
@@ -877,12 +895,15 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
             // lane 5 (feeds the cost) -- one instruction stream when one wave does both
             const bool want_dx = do_chain && l == 0 && !terminal, want_rs = do_reg && l == 5 && tk.state_w() != 0.0;
             if (run && (want_dx || want_rs)) {
-                double d[kNDX];
-                state_diff<false>(want_dx ? q.xs : x_reg, q.x, d, nullptr);
+                double d[kNDX], xa[40], xb[40];
+                lds_read_vec40(want_dx ? q.xs : x_reg, xa);
+                lds_read_vec40(q.x, xb);
+                state_diff<false>(xa, xb, d, nullptr);
                 if (want_dx) { UNROLL_RBD for (int i = 0; i < kNDX; ++i) q.dx[i] = d[i]; }
                 else {
-                    double acc = 0.0;
-                    UNROLL_RBD for (int i = 0; i < kNDX; ++i) acc += state_w[i] * d[i] * d[i];
+                    double acc = 0.0, swv[kNDX];
+                    lds_read_vec36(state_w, swv);
+                    UNROLL_RBD for (int i = 0; i < kNDX; ++i) acc += swv[i] * d[i] * d[i];
                     q.bc[2] = tk.state_w() * 0.5 * acc;
                 }
             } else if (run && do_reg && l == 5) q.bc[2] = 0.0;
@@ -892,7 +913,13 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
                 int fid[kFrameSlots];
                 UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) fid[f] = tk.frame_w(f) != 0.0 ? tk.frame_id(f) : -1;
                 PartSum ps;
-                quad_part(m, q.x, fid, l, ps);
+                double xv[40], qj[kLegJoints], vj[kLegJoints];
+                lds_read_vec40(q.x, xv);
+                UNROLL_RBD for (int j = 0; j < kLegJoints; ++j) {      // this lane's leg out of the four, by selects (no indexed registers)
+                    qj[j] = l == 0 ? xv[7 + j] : l == 1 ? xv[10 + j] : l == 2 ? xv[13 + j] : xv[16 + j];
+                    vj[j] = l == 0 ? xv[kNQ + 6 + j] : l == 1 ? xv[kNQ + 9 + j] : l == 2 ? xv[kNQ + 12 + j] : xv[kNQ + 15 + j];
+                }
+                quad_part(m, xv, qj, vj, fid, l, ps);
                 q.part[l][0] = ps.mass;
                 UNROLL_RBD for (int c = 0; c < 3; ++c) q.part[l][1 + c] = ps.h1[c];
                 UNROLL_RBD for (int c = 0; c < 6; ++c) q.part[l][4 + c] = ps.hO[c];
@@ -903,8 +930,9 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
             if (NW == 1) __syncthreads();   // with several waves each side hands over inside its own wave (LDS keeps a wave's order)
             // phase 3: feedback u = u - alpha k - K dx, two rows per lane (0..8 own rows l and l + 9), rows fetched a node ahead
             if (run && do_chain && !terminal && l < 9) {
-                double v0 = up0 - al * fp0, v1 = up1 - al * fp1;
-                UNROLL_RBD for (int j = 0; j < kNDX; ++j) { v0 -= kp0[j] * q.dx[j]; v1 -= kp1[j] * q.dx[j]; }
+                double v0 = up0 - al * fp0, v1 = up1 - al * fp1, dxv[kNDX];
+                lds_read_vec36(q.dx, dxv);
+                UNROLL_RBD for (int j = 0; j < kNDX; ++j) { v0 -= kp0[j] * dxv[j]; v1 -= kp1[j] * dxv[j]; }
                 q.u[l] = v0; q.u[l + 9] = v1;
                 ws[us_try + (long)t * kNV + l] = v0; ws[us_try + (long)t * kNV + l + 9] = v1;
                 if (t + 1 < T) {   // rows of the next node travel while this node is evaluated
@@ -920,9 +948,13 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
             if (run && do_chain && l == 6) {
                 double acc = 0.0;
                 if (!terminal) {
-                    UNROLL_RBD for (int i = 0; i < kNV; ++i) acc += ctrl_w[i] * q.u[i] * q.u[i];
+                    double cwv[22], uv[22], xv[40];
+                    lds_read_vec22(ctrl_w, cwv);
+                    lds_read_vec22(q.u, uv);
+                    lds_read_vec40(q.x, xv);
+                    UNROLL_RBD for (int i = 0; i < kNV; ++i) acc += cwv[i] * uv[i] * uv[i];
                     double xn[kNX];
-                    euler_step<false>(q.x, q.u, dtn, xn, nullptr, nullptr);
+                    euler_step<false>(xv, uv, dtn, xn, nullptr, nullptr);
                     bool bad = false;
                     UNROLL_RBD for (int i = 0; i < kNX; ++i) { ws[xs_try + (long)(t + 1) * kNX + i] = xn[i]; q.xn[i] = xn[i]; bad = bad || !(fabs(xn[i]) < INFINITY); }
                     q.bc[1] = bad ? 1.0 : 0.0;
@@ -935,12 +967,22 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
             if (run && do_cost && l == 0) {
                 double M = 0.0, h1[3] = {0, 0, 0}, hO[6] = {0, 0, 0, 0, 0, 0}, fx[kFrameSlots][3];
                 UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) fx[f][0] = fx[f][1] = fx[f][2] = 0.0;
+                constexpr int kPw = 10 + 3 * kFrameSlots;      // 22 doubles per part: five parts = 44 + 44 + 22
+                double2_t pa0[22], pa1[22], pa2[11];
+                lds_read_b128x22(lds_offset(&q.part[0][0]), pa0);
+                lds_read_b128x22(lds_offset(&q.part[2][0]), pa1);
+                lds_read_b128x11(lds_offset(&q.part[4][0]), pa2);
+                auto part_at = [&](int pa, int k) -> double {      // compile-time indices after unrolling
+                    const int e = (pa % 2) * kPw + k;
+                    const double2_t v2 = pa < 2 ? pa0[e >> 1] : pa < 4 ? pa1[e >> 1] : pa2[e >> 1];
+                    return (e & 1) ? v2.y : v2.x;
+                };
                 UNROLL_RBD for (int pa = 0; pa <= kLegs; ++pa) {
-                    M += q.part[pa][0];
-                    UNROLL_RBD for (int c = 0; c < 3; ++c) h1[c] += q.part[pa][1 + c];
-                    UNROLL_RBD for (int c = 0; c < 6; ++c) hO[c] += q.part[pa][4 + c];
+                    M += part_at(pa, 0);
+                    UNROLL_RBD for (int c = 0; c < 3; ++c) h1[c] += part_at(pa, 1 + c);
+                    UNROLL_RBD for (int c = 0; c < 6; ++c) hO[c] += part_at(pa, 4 + c);
                     UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
-                        UNROLL_RBD for (int c = 0; c < 3; ++c) fx[f][c] += q.part[pa][10 + 3 * f + c];
+                        UNROLL_RBD for (int c = 0; c < 3; ++c) fx[f][c] += part_at(pa, 10 + 3 * f + c);
                 }
                 double com[3], t3[3], c = 0.0, acc = 0.0;
                 UNROLL_RBD for (int k = 0; k < 3; ++k) com[k] = h1[k] / M;

@@ -218,7 +218,8 @@ RBD_D void quad_pass1(const RobotModelDev &m, const double *x, const int *fid, P
 // spread one node evaluation over five lanes (forward rollout) and add the parts in LDS.
 struct PartSum { double mass, h1[3], hO[6], fx[kFrameSlots][3]; int fhit[kFrameSlots]; };
 
-RBD_D void quad_part(const RobotModelDev &m, const double *x, const int *fid, int part, PartSum &o) {
+// x: the state with compile-time indices only (registers); qj / vj: the three joint angles / rates of leg `part`
+RBD_D void quad_part(const RobotModelDev &m, const double *x, const double *qj, const double *vj, const int *fid, int part, PartSum &o) {
     double Rb[9], pb[3], Vb[6];
     quat_to_R(x + 3, Rb);
     pb[0] = x[0]; pb[1] = x[1]; pb[2] = x[2];
@@ -261,7 +262,7 @@ RBD_D void quad_part(const RobotModelDev &m, const double *x, const int *fid, in
         const int i = kLegJoints * part + j;      // runtime leg: model / state reads are indexed, locals are not
         double R[9], p[3], S[6], V[6];
         load_body(m, i + 1, br);
-        joint_step_r(m, br, i, x[7 + i], v[6 + i], Rp, pp, Vp, R, p, S, V);
+        joint_step_r(m, br, i, qj[j], vj[j], Rp, pp, Vp, R, p, S, V);
         body_momentum_r(br, R, p, V, o.mass, o.h1, o.hO);
         frames_on(i + 1, R, p);
         UNROLL_RBD for (int c = 0; c < 9; ++c) Rp[c] = R[c];
