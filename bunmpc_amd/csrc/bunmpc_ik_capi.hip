@@ -189,6 +189,7 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run) {
         const int chunk = active <= g_spec_line_search_below ? kTailChunk : 1;
         a.fwd_spec = active <= g_spec_line_search_below / 3 ? 3 : active <= g_spec_line_search_below ? 2 : 0;
         for (int k = 0; k < chunk && it < a.maxiter; ++k, ++it) {
+            HIP_TRY(bunmpc::ik_launch_state(a, st));
             HIP_TRY(bunmpc::ik_launch_calcdiff(a, st));
             HIP_TRY(bunmpc::ik_launch_backward(a, st));
             HIP_TRY(bunmpc::ik_launch_forward(a, st));

@@ -174,6 +174,62 @@ struct alignas(16) CalcNode {         // per node of the workgroup
 constexpr int kCalcNodes = 2;
 struct alignas(16) CalcLds { CalcNode nd[kCalcNodes]; RobotModelDev m; };
 
+// State regularisation residual (+ its Jlog6 block) and the Euler step (+ its Jintegrate blocks, written to the workspace)
+// of node tw: the scalar chain of the derivative pass.  Returns the node's state + control cost.
+__device__ __forceinline__ double node_state_terms(const IkBatchArgs &a, long b, int tw, double *ws, const IkLayout &L, const double *x,
+                                                   const double *u, const double *state_w0, const double *ctrl_w0, const double *x_reg0,
+                                                   const NodeTasks &tkw, double *rs, double *Jl) {
+    const bool terminal_w = tw == a.T;
+    const double dtw = terminal_w ? 0.0 : a.dt[b * a.T + tw];
+    const double wst = tkw.state_w(), wu = tkw.ctrl_w();
+    const double *state_w = state_w0 + a.sn_state_w * tw, *ctrl_w = ctrl_w0 + a.sn_ctrl_w * tw;
+    double cost = 0.0;
+    if (wst != 0.0) {
+        state_diff<true>(x_reg0 + a.sn_x_reg * tw, x, rs, Jl);
+        double acc = 0.0;
+        UNROLL_RBD for (int i = 0; i < kNDX; ++i) acc += state_w[i] * rs[i] * rs[i];
+        cost += wst * 0.5 * acc;
+    } else {
+        UNROLL_RBD for (int i = 0; i < kNDX; ++i) rs[i] = 0.0;
+        UNROLL_RBD for (int i = 0; i < 36; ++i) Jl[i] = (i % 7 == 0) ? 1.0 : 0.0;
+    }
+    if (!terminal_w) {
+        double acc = 0.0;
+        UNROLL_RBD for (int i = 0; i < kNV; ++i) acc += ctrl_w[i] * u[i] * u[i];
+        cost += wu * 0.5 * acc;
+        double xn[kNX], A6[36], B6[36];
+        euler_step<true>(x, u, dtw, xn, A6, B6);
+        UNROLL_RBD for (int i = 0; i < kNX; ++i) ws[L.xnext + (long)tw * kNX + i] = xn[i];
+        UNROLL_RBD for (int i = 0; i < 36; ++i) { ws[L.A6 + (long)tw * 36 + i] = A6[i]; ws[L.B6 + (long)tw * 36 + i] = B6[i]; }
+    }
+    return cost;
+}
+
+// ... for all nodes of all problems, ONE LANE PER NODE, launched before ik_calcdiff_kernel.  Inside that kernel (where it used
+// to run, on lanes 0 and 32 of wave 1) this chain kept two lanes of a wave busy, and in the bulk iterations -- where
+// calcdiff is bound by instruction issue -- those two lanes cost a quarter of the workgroup's issue slots; here 64 nodes
+// share every instruction.  One code path whatever the number of active problems, so a problem's results do not depend
+// on its batch (the few microseconds of an extra launch per tail iteration are the price).
+__global__ __launch_bounds__(64) void ik_state_kernel(const IkBatchArgs a) {
+    const int nn = a.T + 1;
+    const long idx = (long)blockIdx.x * 64 + threadIdx.x;
+    const long b = idx / nn;
+    const int tw = (int)(idx % nn);
+    if (b >= a.B) return;
+    const IkLayout L = IkLayout::make(a.T);
+    double *ws = a.ws + b * L.total;
+    if (ws[L.scal + S_DONE] != 0.0 || ws[L.scal + S_RECALC] == 0.0) return;
+    double x[kNX], u[kNV], rs[kNDX], Jl[36];
+    UNROLL_RBD for (int i = 0; i < kNX; ++i) x[i] = ws[L.xs + (long)tw * kNX + i];
+    UNROLL_RBD for (int i = 0; i < kNV; ++i) u[i] = tw == a.T ? 0.0 : ws[L.us + (long)tw * kNV + i];
+    NodeTasks tkw{a.tasks + (b * nn + tw) * kNodeTaskDoubles};
+    const double cost = node_state_terms(a, b, tw, ws, L, x, u, batch_ptr(a.state_w, a.s_state_w, b), batch_ptr(a.ctrl_w, a.s_ctrl_w, b),
+                                         a.x_reg + b * a.s_x_reg, tkw, rs, Jl);
+    UNROLL_RBD for (int i = 0; i < kNDX; ++i) ws[L.nrs + (long)tw * kNDX + i] = rs[i];
+    UNROLL_RBD for (int i = 0; i < 6; ++i) UNROLL_RBD for (int k = 0; k < 6; ++k) ws[L.njl + (long)tw * 36 + 6 * i + k] = Jl[6 * k + i];
+    ws[L.ncs + tw] = cost;
+}
+
 // Workgroup = two waves for TWO nodes of a problem.  Wave 0: lanes 0..17 (node A) and 32..49 (node B) each walk their
 // own part of the robot once (base lanes the base body, joint lanes their leg), the five part sums of a node meet in
 // LDS, every lane finishes its column.  Wave 1, meanwhile, on lanes 0 and 32: the state residual with its Jlog6 block
@@ -231,31 +287,12 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a
             UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
                 if (pw.fhit[f]) { UNROLL_RBD for (int c = 0; c < 3; ++c) qw.fx[f][c] = pw.fx[f][c]; }
         }
-    } else if (wave == 1 && wvalid && hl == 0) {   // state residual + its Jacobian block, Euler step, their part of the node cost
-        const double wst = tkw.state_w(), wu = tkw.ctrl_w();
-        const double *state_w = state_w0 + a.sn_state_w * tw, *ctrl_w = ctrl_w0 + a.sn_ctrl_w * tw;
-        double rs[kNDX], Jl[36], cost = 0.0;
-        if (wst != 0.0) {
-            state_diff<true>(x_reg0 + a.sn_x_reg * tw, qw.x, rs, Jl);
-            double acc = 0.0;
-            UNROLL_RBD for (int i = 0; i < kNDX; ++i) acc += state_w[i] * rs[i] * rs[i];
-            cost += wst * 0.5 * acc;
-        } else {
-            UNROLL_RBD for (int i = 0; i < kNDX; ++i) rs[i] = 0.0;
-            UNROLL_RBD for (int i = 0; i < 36; ++i) Jl[i] = (i % 7 == 0) ? 1.0 : 0.0;
+    } else if (wave == 1 && wvalid) {   // state residual, its Jlog6 block (transposed) and the state + control cost: from ik_state_kernel
+        for (int i = hl; i < kNDX; i += 32) {
+            qw.rs[i] = ws[L.nrs + (long)tw * kNDX + i];
+            (&qw.JlT[0][0])[i] = ws[L.njl + (long)tw * 36 + i];      // stored transposed already
         }
-        UNROLL_RBD for (int i = 0; i < kNDX; ++i) qw.rs[i] = rs[i];
-        UNROLL_RBD for (int i = 0; i < 6; ++i) UNROLL_RBD for (int k = 0; k < 6; ++k) qw.JlT[i][k] = Jl[6 * k + i];
-        if (!terminal_w) {
-            double acc = 0.0;
-            UNROLL_RBD for (int i = 0; i < kNV; ++i) acc += ctrl_w[i] * qw.u[i] * qw.u[i];
-            cost += wu * 0.5 * acc;
-            double xn[kNX], A6[36], B6[36];
-            euler_step<true>(qw.x, qw.u, dtw, xn, A6, B6);
-            UNROLL_RBD for (int i = 0; i < kNX; ++i) ws[L.xnext + (long)tw * kNX + i] = xn[i];
-            UNROLL_RBD for (int i = 0; i < 36; ++i) { ws[L.A6 + (long)tw * 36 + i] = A6[i]; ws[L.B6 + (long)tw * 36 + i] = B6[i]; }
-        }
-        qw.cost_sc = cost;
+        if (hl == 0) qw.cost_sc = ws[L.ncs + tw];
     }
     __syncthreads();
     PSTAMP(1)
@@ -1141,6 +1178,11 @@ hipError_t ik_launch_publish_active(const int *active, int *host_word_dev, hipSt
 }
 hipError_t ik_launch_init(const IkBatchArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(ik_init_kernel, dim3((a.B + 63) / 64), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t ik_launch_state(const IkBatchArgs &a, hipStream_t st) {
+    const long n = (long)a.B * (a.T + 1);
+    hipLaunchKernelGGL(ik_state_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 hipError_t ik_launch_calcdiff(const IkBatchArgs &a, hipStream_t st) {

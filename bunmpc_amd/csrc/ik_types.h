@@ -45,7 +45,7 @@ constexpr int kTrySlots = 4;
 // Layout of the per-problem DDP workspace in HBM (doubles), T = number of running nodes.
 struct IkLayout {
     int T;
-    long xs, us, xs_try, us_try, fs, xnext, Lx, Lxx, Lu, Luu, A6, B6, K, kff, Qu, Quuk, scal, total;
+    long xs, us, xs_try, us_try, fs, xnext, Lx, Lxx, Lu, Luu, A6, B6, K, kff, Qu, Quuk, scal, nrs, njl, ncs, total;
     __host__ __device__ static IkLayout make(int T) {
         IkLayout l; l.T = T;
         long o = 0;
@@ -59,6 +59,8 @@ struct IkLayout {
         l.K = take((long)T * kNV * kNDX); l.kff = take((long)T * kNV);
         l.Qu = take((long)T * kNV); l.Quuk = take((long)T * kNV);
         l.scal = take(16);
+        // per node, written by ik_state_kernel for ik_calcdiff_kernel (bulk iterations): state residual, its Jlog6 block, cost part
+        l.nrs = take((long)(T + 1) * kNDX); l.njl = take((long)(T + 1) * 36); l.ncs = take((long)T + 1);
         l.total = o;
         return l;
     }
@@ -85,6 +87,7 @@ struct IkBatchArgs {
 };
 
 hipError_t ik_launch_init(const IkBatchArgs &a, hipStream_t s);
+hipError_t ik_launch_state(const IkBatchArgs &a, hipStream_t s);      // before every calcdiff
 hipError_t ik_launch_calcdiff(const IkBatchArgs &a, hipStream_t s);
 hipError_t ik_launch_backward(const IkBatchArgs &a, hipStream_t s);
 hipError_t ik_launch_forward(const IkBatchArgs &a, hipStream_t s);
