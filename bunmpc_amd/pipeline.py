@@ -4,8 +4,8 @@ on separate HIP streams fill that idle time -- the tail of one overlaps the bulk
 a host thread because the batched DDP loop is host-driven (it looks at the active-problem counter between iterations):
 the C-ABI call releases the GIL and waits on its own stream only, its scratch state is thread-local.
 
-Measured (MI355X, `bench.py` `multi_stream`): 3 streams give 1.28x the single-stream throughput on Solo12 H=20 / H_ik=10
-(B = 4096 per batch) and 1.73x on the synthetic Go2 H=60 / H_ik=30 (B = 1024); a 4th stream loses again (HIP multiplexes
+Measured (MI355X, `bench.py` `multi_stream`): 3 streams give 1.2-1.3x the single-stream throughput on Solo12 H=20 / H_ik=10
+(B = 4096 per batch) and 1.7x on the synthetic Go2 H=60 / H_ik=30 (B = 1024); a 4th stream loses again (HIP multiplexes
 streams onto 4 hardware queues, one of which the default stream holds)."""
 import threading
 
