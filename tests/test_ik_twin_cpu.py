@@ -1,0 +1,159 @@
+"""The two CPU restatements of the whole-body IK-DDP against each other: oracle/ik_ddp_oracle.c (compiled, spatial-inertia
+kinematics, ad-series SE(3) Jacobians, dense crocoddyl-shaped Riccati) vs oracle/ik_ddp_np.py + oracle/rbd_np.py (numpy,
+composite (m, c, I) triples, Barfoot closed forms).  PARITY UNPINNED: crocoddyl 1.9.0 / pinocchio 2.6.9 are absent and the
+reference holds no vectors for this path; two independently written restatements that take the same discrete path
+(iterations, accepted step lengths, regularisation) and agree to rounding are the strongest evidence available here."""
+import dataclasses
+import os
+
+import numpy as np
+import pytest
+
+from bunmpc_amd import problems, urdf_model
+from oracle import ik_ddp_np, ik_oracle_c as ic, oracle_c, rbd_np as rb
+from tests.util import rel_l2
+
+ROBOTS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bunmpc_amd", "robots")
+
+
+@pytest.fixture(scope="module")
+def solo():
+    model = urdf_model.RobotModel.from_json(open(os.path.join(ROBOTS, "solo12.json")).read())
+    return model, ic.Model(model)
+
+
+@pytest.fixture(scope="module")
+def go2():
+    model = urdf_model.RobotModel.from_json(open(os.path.join(ROBOTS, "go2.json")).read())
+    return model, ic.Model(model)
+
+
+def np_problem(model, wb, i, X):
+    """problem i of a whole-body batch for the numpy DDP, tracking the centroidal solution X (H+1, 9)"""
+    T, names = wb.ik_T, list(model.frames)
+    prob = ik_ddp_np.IKProblem(model, T)
+    for t in range(T + 1):
+        tk = wb.ik_tasks[i, t]
+        for s in range(4):
+            if tk[5 * s] != 0:
+                prob._add(t, "f%d" % s, ("frame", tk[5 * s], (names[int(tk[5 * s + 1])], tk[5 * s + 2:5 * s + 5])))
+        prob._add(t, "com", ("com", tk[20], X[t, 0:3]))
+        prob._add(t, "mom", ("mom", tk[24], np.concatenate([wb.dyn.m * X[t, 3:6], X[t, 6:9]])))
+        prob._add(t, "x", ("state", tk[31], (wb.state_w[0], wb.x_reg[i])))
+        prob._add(t, "u", ("ctrl", tk[32], wb.ctrl_w[0]))
+    prob.setup_costs(wb.dyn.dt[i, :T])
+    return prob
+
+
+def test_kinematic_quantities_agree(solo):
+    model, m = solo
+    rng = np.random.default_rng(3)
+    for _ in range(4):
+        q = rb.integrate(model, rb.neutral(model), np.concatenate([0.3 * rng.standard_normal(6), rng.standard_normal(12)]))
+        x = np.concatenate([q, rng.standard_normal(18)])
+        kq, kin = ic.kin_quantities(m, x), rb.Kin(model, x[:19], x[19:])
+        assert np.abs(kq["com"] - kin.com).max() < 1e-14
+        assert np.abs(kq["hg"] - kin.centroidal_momentum()).max() < 1e-13
+        assert np.abs(kq["Ag"] - kin.centroidal_map()).max() < 1e-13
+        assert np.abs(kq["Jc"] - kin.jacobian_com()).max() < 1e-14
+        assert np.abs(kq["dh"] - kin.dh_dq()).max() < 1e-12
+        for name in ("FL_FOOT", "HR_FOOT", "base_link"):
+            pos, J = ic.frame(m, x, model.frame_id(name))
+            assert np.abs(pos - kin.frame_placement(name)[1]).max() < 1e-14
+            assert np.abs(J - kin.frame_jacobian_lin(name)).max() < 1e-14
+        c9 = ic.centroidal_state(m, x)[0]
+        assert np.abs(c9 - np.concatenate([kin.com, kin.vcom(), kin.centroidal_momentum()[3:]])).max() < 1e-13
+
+
+def test_state_operators_and_se3_jacobians(solo):
+    """integrate / diff and the Jacobians: the C side builds J_r(xi) from the ad-series and Jlog6 as its inverse, the numpy
+    side from Barfoot's closed forms -- and both against finite differences of the C operators themselves."""
+    model, m = solo
+    rng = np.random.default_rng(5)
+    for scale in (1e-6, 0.05, 0.6):
+        x0 = np.concatenate([rb.integrate(model, rb.neutral(model), 0.4 * rng.standard_normal(18)), rng.standard_normal(18)])
+        x1 = rb.state_integrate(model, x0, scale * rng.standard_normal(36))
+        dx = scale * rng.standard_normal(36)
+        so = ic.state_ops(m, x0, x1, dx)
+        assert np.abs(so["diff"] - rb.state_diff(model, x0, x1)).max() < 1e-13
+        assert np.abs(so["xint"] - rb.state_integrate(model, x0, dx)).max() < 1e-14
+        J1, J2 = rb.state_jintegrate(model, x0, dx)
+        assert np.abs(so["A6"] - J1[:6, :6]).max() < 1e-13 and np.abs(so["B6"] - J2[:6, :6]).max() < 1e-12
+        assert np.abs(so["Jl"] - rb.state_jdiff_second(model, x0, x1)[:6, :6]).max() < 1e-11
+        # finite differences of the C operators: d diff(x0, x1 (+) e)/de = Jl;  x (+) (dx + e) = (x (+) dx) (+) B6 e
+        h = 1e-6
+        for k in range(6):
+            e = np.zeros(36); e[k] = h
+            dp = ic.state_ops(m, x0, rb.state_integrate(model, x1, e), dx)["diff"]
+            dm = ic.state_ops(m, x0, rb.state_integrate(model, x1, -e), dx)["diff"]
+            assert np.abs((dp - dm)[:6] / (2 * h) - so["Jl"][:, k]).max() < 1e-7
+            xp = ic.state_ops(m, x0, x1, dx + e)["xint"]
+            xm = ic.state_ops(m, x0, x1, dx - e)["xint"]
+            fd = ic.state_ops(m, xm, xp, dx)["diff"][:6] / (2 * h)
+            assert np.abs(fd - so["B6"][:, k]).max() < 1e-7
+
+
+def test_node_derivatives_agree(solo):
+    model, m = solo
+    wb = problems.make_wb_batch(model, 2)
+    T = wb.ik_T
+    X = np.tile(wb.dyn.x_init[1], (wb.dyn.H + 1, 1))
+    prob = np_problem(model, wb, 1, X)
+    tasks = np.array(wb.ik_tasks[1])
+    tasks[:, 21:24] = X[:T + 1, 0:3]
+    tasks[:, 25:28] = wb.dyn.m * X[:T + 1, 3:6]
+    tasks[:, 28:31] = X[:T + 1, 6:9]
+    rng = np.random.default_rng(1)
+    for t in (0, 3, T):
+        x = rb.state_integrate(model, wb.x[1], 0.1 * rng.standard_normal(36))
+        u = rng.standard_normal(18)
+        ref = ik_ddp_np.node_calc(prob, t, x, None if t == T else u, diff=True)
+        got = ic.node(m, T, t, wb.dyn.dt[1, :T], tasks, wb.state_w[0], wb.x_reg[1], wb.ctrl_w[0], x, u)
+        assert abs(got["cost"] - ref["cost"]) <= 1e-13 * abs(ref["cost"])
+        assert np.abs(got["Lx"] - ref["Lx"]).max() <= 1e-12 * np.abs(ref["Lx"]).max()
+        assert np.abs(got["Lxx"] - ref["Lxx"]).max() <= 1e-12 * np.abs(ref["Lxx"]).max()
+        if t < T:
+            assert np.abs(got["xnext"] - ref["xnext"]).max() < 1e-14
+            assert np.abs(got["Fx"] - ref["Fx"]).max() < 1e-12 and np.abs(got["Fu"] - ref["Fu"]).max() < 1e-12
+            assert np.abs(got["Lu"] - ref["Lu"]).max() <= 1e-13 * np.abs(ref["Lu"]).max()
+            assert np.abs(got["Luu"] - ref["Luu"]).max() <= 1e-13 * np.abs(ref["Luu"]).max()
+
+
+def test_ddp_twins_take_the_same_path_solo12(solo):
+    model, m = solo
+    B = 3
+    wb = problems.make_wb_batch(model, B)
+    ref = oracle_c.solve_batch(wb.dyn, num_iters=10)
+    r = ic.solve_wb_batch(m, wb, ref["X"], trace=True)
+    assert np.all(r["status"] == 0)
+    for i in range(B):
+        rn = ik_ddp_np.solve_ddp(np_problem(model, wb, i, ref["X"][i].reshape(-1, 9)), wb.x[i])
+        assert rn["converged"] and rn["iters"] == r["iters"][i], (i, rn["iters"], r["iters"][i])
+        assert abs(rn["cost"] - r["cost"][i]) <= 1e-12 * abs(rn["cost"])
+        assert rn["reg"] == r["reg"][i]
+        assert rel_l2(r["xs"][i].reshape(-1), np.array(rn["xs"]).reshape(-1)) < 1e-12
+        assert rel_l2(r["us"][i].reshape(-1), np.array(rn["us"]).reshape(-1)) < 1e-10
+        tr = r["trace"][i, :r["iters"][i]]
+        assert np.all(np.diff(tr[1:, 0]) <= 1e-12 * tr[1:-1, 0])       # the cost never increases once feasible
+
+
+def test_ddp_twins_go2_long_horizon(go2):
+    """BASELINE config 5's shape (synthetic Go2, H = 60, H_ik = 30), one problem through both restatements"""
+    model, m = go2
+    wb = problems.make_wb_batch(model, 1, gait=dataclasses.replace(problems.TROT, nom_ht=0.30, gait_horizon=6.0), wb=problems.GO2_WB)
+    assert wb.ik_T == 30
+    ref = oracle_c.solve_batch(wb.dyn, num_iters=10, fast=True)
+    r = ic.solve_wb_batch(m, wb, ref["X"])
+    rn = ik_ddp_np.solve_ddp(np_problem(model, wb, 0, ref["X"][0].reshape(-1, 9)), wb.x[0])
+    assert rn["iters"] == r["iters"][0] and (r["status"][0] == 0) == rn["converged"]
+    assert abs(rn["cost"] - r["cost"][0]) <= 1e-10 * abs(rn["cost"])
+    assert rel_l2(r["xs"][0].reshape(-1), np.array(rn["xs"]).reshape(-1)) < 1e-9
+
+
+def test_batch_is_thread_count_independent(solo):
+    model, m = solo
+    wb = problems.make_wb_batch(model, 6)
+    X = np.tile(wb.dyn.x_init[:, None, :], (1, wb.dyn.H + 1, 1)).reshape(6, -1)
+    a = ic.solve_wb_batch(m, wb, X, nthreads=1)
+    b = ic.solve_wb_batch(m, wb, X, nthreads=4)
+    assert np.array_equal(a["xs"], b["xs"]) and np.array_equal(a["iters"], b["iters"])
