@@ -1,20 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- MPC solves/sec of the batched BiConvex MPC solve on MI355X.
 
-One "step" = one pass of the hot path over one batch: B independent
-BiconvexMP.optimize(x_init, 10) solves (Solo12 trot, H = 20, fp64, perturbed initial
-conditions; SURVEY.md 8d config 2 at the batch size of north_star's target, 4096 per GPU)
-in ONE kernel launch, inputs already resident in HBM, cold start as
-KinoDynMP::set_warm_starts does.  Multi-GPU: one process per GPU, the batch is sharded
-(rank r solves problems [r*B, (r+1)*B)), no data-path collective (the solves are
-independent); RCCL only carries the timing/telemetry reductions.
+One "step" = one pass of the hot path over one batch.  Default workload (`--workload biconvex`): B independent
+BiconvexMP.optimize(x_init, 10) solves (Solo12 trot, H = 20, fp64, perturbed initial conditions; SURVEY.md 8d config 2 at
+the batch size of north_star's target, 4096 per GPU) in ONE kernel launch, inputs already resident in HBM, cold start as
+KinoDynMP::set_warm_starts does.  `--workload kinodyn` makes the full KinoDynMP.optimize (centroidal ADMM + whole-body
+IK-DDP; BASELINE config 5's shape with `--kinodyn-config go2_h60`) the measured line instead.
+
+Multi-GPU: one process per GPU, every leg shards its batch (rank r solves problems [r*B, (r+1)*B)), no data-path
+collective (the solves are independent); RCCL only carries the timing / telemetry reductions.  Every leg is bracketed by a
+barrier + synchronize on both sides and reports the MAX over ranks.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with
-  roofline      HBM view of the ADMM kernel (algorithmic bytes per launch / measured kernel
-                time; the path is fp64-VALU/latency bound, so `valu` carries the meaningful
-                fraction) and
-  cpu_baseline  the CPU restatement of the reference algorithm (oracle/, "port") timed on
-                this box's host cores on a bounded sample of the same workload.
+  roofline      HBM view of the dominant kernel (algorithmic bytes / measured kernel time; the path is fp64-VALU / latency
+                bound, so `valu` carries the meaningful fraction) and
+  cpu_baseline  the CPU restatement of the reference algorithm (oracle/, "port") timed on this box's host cores on a bounded
+                sample of the same workload (rank 0, N = 1 only).
+The KinoDyn legs inside the line carry their own `roofline` and `cpu_baseline` objects.
 """
 import argparse
 import json
@@ -30,6 +32,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TF = 78.6    # MI355X vector fp64 peak (spec)
+METRIC_SHAPE = {"solo12_trot": "Solo12 trot H=20", "solo12_mixed": "Solo12 mixed gaits (trot/bound/pace) H=20", "go2_bound": "Go2 bound H=40",
+                "solo12_trot_nominal": "Solo12 trot H=20 (nominal)"}
 
 
 def flops_from_stats(stats, H, E=4):
@@ -52,10 +56,20 @@ def host_cores():
     return n
 
 
+def build_oracles():
+    """the CPU checkers are rebuilt on the box that times them (-march=native must match its cores); the prebuilt files
+    are used when no compiler is there"""
+    from oracle import ik_oracle_c, oracle_c
+    for mod in (oracle_c, ik_oracle_c):
+        try:
+            mod.build(force=True)
+        except Exception:          # noqa: BLE001 -- the prebuilt library travelled with the tree
+            mod.build()
+
+
 def cpu_baseline(config, H_iters, sample, maxit):
     from bunmpc_amd import problems
     from oracle import oracle_c
-    oracle_c.build()
     cores = host_cores()
     b = problems.make_batch(config, sample)
     oracle_c.solve_batch(b.slice(0, min(cores, sample)), num_iters=H_iters, maxit=maxit, nthreads=cores)  # warm-up
@@ -80,9 +94,37 @@ def cpu_baseline(config, H_iters, sample, maxit):
                                             "the reference itself is the explicit-Hessian formulation above"}}
 
 
-def p50_latency(config, num_iters, reps=60):
+def kinodyn_cpu_baseline(model, wb, admm_iters, maxit, sample):
+    """KinoDynMP::optimize on the host: centroidal state of (q, v), the strict C restatement of the ADMM, the tracking
+    references, then the compiled IK-DDP twin (oracle/ik_ddp_oracle.c: dense crocoddyl-shaped Riccati) -- one problem per
+    OpenMP thread, on the first `sample` problems of the leg's batch."""
+    from oracle import ik_oracle_c as ic, oracle_c
+    cores = host_cores()
+    sub = wb.take(np.arange(min(sample, wb.dyn.B)))
+    m = ic.Model(model)
+    n = sub.dyn.B
+
+    def run(w, threads):
+        t0 = time.perf_counter()
+        w.dyn.x_init[:] = ic.centroidal_state(m, w.x)
+        r = oracle_c.solve_batch(w.dyn, num_iters=admm_iters, maxit=maxit, nthreads=threads)
+        t1 = time.perf_counter()
+        k = ic.solve_wb_batch(m, w, r["X"], nthreads=threads)
+        return t1 - t0, time.perf_counter() - t1, k
+    run(sub.take(np.arange(min(cores, n))), cores)
+    t_dyn, t_ik, k = run(sub, cores)
+    l_dyn, l_ik, _ = run(sub.take(np.arange(min(2, n))), 1)
+    return {"value": n / (t_dyn + t_ik), "unit": "KinoDynMP solves/s", "cores": cores, "kind": "port",
+            "sample": "%d problems of the same workload, one solve per OpenMP thread over %d threads: strict centroidal restatement "
+                      "(oracle/biconvex_oracle.c) + compiled IK-DDP twin (oracle/ik_ddp_oracle.c); not the reference binary "
+                      "(needs Eigen / pinocchio / crocoddyl, absent)" % (n, cores),
+            "dyn_seconds": t_dyn, "ik_seconds": t_ik, "single_core_ms_per_solve": (l_dyn + l_ik) / min(2, n) * 1e3,
+            "ddp_iters_mean": float(k["iters"].mean()), "ddp_not_converged": int((k["status"] != 0).sum())}
+
+
+def p50_latency(config, num_iters, reps=200, warm=20):
     """Batch-1 wall time of BiconvexMP.optimize through the drop-in class, incl. H2D of the
-    inputs and D2H of X/F/P."""
+    inputs and D2H of X/F/P (p50 over >= 200 repeats after 20 warm-ups)."""
     from bunmpc_amd import problems
     from bunmpc_amd.biconvex_mpc_cpp import BiconvexMP
     b = problems.make_batch(config, 1)
@@ -91,7 +133,7 @@ def p50_latency(config, num_iters, reps=60):
     mp.set_rho(b.rho)
     X0, F0, P0 = b.warm_start()
     ts = []
-    for r in range(reps + 5):
+    for r in range(reps + warm):
         for i in range(H):
             mp.set_contact_plan(b.cnt_plan[0, i], b.dt[0, i])
         mp.create_bound_constraints(b.bounds[0], 15.0, 15.0, 15.0)
@@ -102,11 +144,44 @@ def p50_latency(config, num_iters, reps=60):
         t0 = time.perf_counter()
         mp.optimize(b.x_init[0], num_iters)
         ts.append(time.perf_counter() - t0)
-    return float(np.median(ts[5:]) * 1e3)
+    ts = np.array(ts[warm:]) * 1e3
+    return {"p50_ms": float(np.median(ts)), "p90_ms": float(np.quantile(ts, 0.9)), "reps": reps, "warmups": warm,
+            "what": "BiconvexMP.optimize(x_init, %d) on one problem through the drop-in class: H2D of the inputs, one launch, "
+                    "D2H of X / F / P" % num_iters}
+
+
+def kinodyn_latency(reps=(60, 30), warm=5):
+    """p50 of the reference's own call, kd.optimize(q, v, N, 1) (abstract_cyclic_gen.py:663; N = 100 there, 10 in the
+    benchmark configs), through the drop-in harness SoloMpcGaitGen on one Solo12: the wall time of KinoDynMP.optimize
+    itself (plan and cost set-up excluded, as the reference's solve_times[2] counts it) against the 50 ms replanning
+    budget (simulation.py:44)."""
+    from bunmpc_amd import problems, urdf_model
+    from bunmpc_amd.cyclic_gen import SoloMpcGaitGen
+    model = urdf_model.RobotModel.from_json(open(os.path.join(ROOT, "bunmpc_amd", "robots", "solo12.json")).read())
+    q0 = problems.SOLO12_Q0.copy()
+    gg = SoloMpcGaitGen(model, model, np.concatenate([q0, np.zeros(18)]), 0.05, q0)
+    gg.update_gait_params(problems.TROT, 0.0)
+    gg.kd.compute_solve_times()
+    out = {"budget_ms": 50.0}
+    import contextlib
+    import io
+    for N, n in zip((10, 100), reps):
+        ts, tot = [], []
+        for r in range(n + warm):
+            q, v = q0.copy(), np.zeros(18)
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):        # compute_solve_times prints, as the reference does
+                gg.optimize(q, v, round(0.05 * (r % 10), 3), np.array([0.2, 0.0, 0.0]), 0.0, dyn_iters=N)
+            tot.append(time.perf_counter() - t0)
+            ts.append(gg.kd.return_solve_times()[2])
+        ts, tot = np.array(ts[warm:]) * 1e3, np.array(tot[warm:]) * 1e3
+        out["N=%d" % N] = {"kd_optimize_p50_ms": float(np.median(ts)), "kd_optimize_p90_ms": float(np.quantile(ts, 0.9)),
+                           "harness_call_p50_ms": float(np.median(tot)), "reps": n, "warmups": warm}
+    return out
 
 
 def pmc_traffic(workload_key):
-    """HBM bytes per launch measured with rocprofv3 PMC counters for exactly this workload
+    """HBM bytes per launch (per solve for the KinoDyn legs) measured with rocprofv3 PMC counters for exactly this workload
     (profiles/pmc_traffic.json), or None when no such measurement is committed."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
@@ -115,59 +190,113 @@ def pmc_traffic(workload_key):
         return None
 
 
+def ik_algorithmic_bytes(T, E=4):
+    """SURVEY.md 8d, the IK part of one KinoDynMP.optimize: in q, v (37) + per-knot foot targets / flags 4 E H_ik,
+    out xs 37 (H_ik + 1) + us 18 H_ik doubles"""
+    return 8 * (37 + 4 * E * T + 37 * (T + 1) + 18 * T)
+
+
+class Dist:
+    """the rank bookkeeping every leg shares: barrier + synchronize brackets, MAX / SUM reductions of scalars"""
+
+    def __init__(self, torch, dist, dev, world, rank, rehearsal):
+        self.torch, self.dist, self.dev, self.world, self.rank, self.rehearsal = torch, dist, dev, world, rank, rehearsal
+
+    def sync(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def reduce(self, values, op):
+        t = self.torch.tensor([float(v) for v in values], dtype=self.torch.float64, device="cpu" if self.rehearsal else self.dev)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
+        return [float(v) for v in t]
+
+    def timed(self, fn, steps, warmup):
+        """W untimed + exactly K timed calls of fn between barrier + synchronize brackets; seconds, MAX over ranks"""
+        for _ in range(warmup):
+            fn()
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        self.sync()
+        return self.reduce([time.perf_counter() - t0], "MAX")[0]
+
+
 _POOLS = {}
 
 
-def kinodyn_leg(dev, B, admm_iters, maxit, config="solo12_h20", steps=3, n_streams=3):
-    """Informational: the full KinoDynMP.optimize (centroidal ADMM + whole-body IK-DDP) over B perturbed
-    whole-body states, device resident.  solo12_h20: Solo12 trot, H = 20, H_ik = 10;
-    go2_h60: BASELINE config 5's shape (synthetic Go2, trot, H = 60, H_ik = 30)."""
+def kinodyn_leg(D, B, admm_iters, maxit, config="solo12_h20", steps=3, warmup=1, n_streams=3, cpu_sample=0):
+    """The full KinoDynMP.optimize (centroidal ADMM + whole-body IK-DDP) over B perturbed whole-body states per GPU, device
+    resident, rank r owning problems [r B, (r + 1) B).  solo12_h20: Solo12 trot, H = 20, H_ik = 10; go2_h60: BASELINE
+    config 5's shape (synthetic Go2, trot, H = 60, H_ik = 30)."""
     import dataclasses
-    import torch
-    from bunmpc_amd import problems, urdf_model
+    from bunmpc_amd import _lib, batch as bb, problems, urdf_model
     from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
+    torch, dev = D.torch, D.dev
     robot = "go2" if config == "go2_h60" else "solo12"
     model = urdf_model.RobotModel.from_json(open(os.path.join(ROOT, "bunmpc_amd", "robots", robot + ".json")).read())
+    first = D.rank * B
     if config == "go2_h60":
-        wb = problems.make_wb_batch(model, B, gait=dataclasses.replace(problems.TROT, nom_ht=0.30, gait_horizon=6.0),
+        wb = problems.make_wb_batch(model, B, first=first, gait=dataclasses.replace(problems.TROT, nom_ht=0.30, gait_horizon=6.0),
                                     wb=problems.GO2_WB)
     else:
-        wb = problems.make_wb_batch(model, B)
+        wb = problems.make_wb_batch(model, B, first=first)
     kb = KinoDynDeviceBatch(wb, model, device=dev, num_iters=admm_iters, maxit=maxit)
-    kb.solve()
+    dt = D.timed(kb.solve, steps, warmup) / steps
+    dt_ik = D.timed(kb.solve_ik_only, steps, 0) / steps
+    # where the time of one batch solve goes: events around every kernel of the DDP loop (a separate, untimed pass)
+    lib = _lib.lib()
+    lib.bmpc_ik_set_profile(1)
+    kb.solve_ik_only()
     torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        kb.solve()
-    torch.cuda.synchronize(dev)
-    dt = (time.perf_counter() - t0) / steps
-    t1 = time.perf_counter()
-    for _ in range(steps):
-        kb.solve_ik_only()
-    torch.cuda.synchronize(dev)
-    dt_ik = (time.perf_counter() - t1) / steps
+    lib.bmpc_ik_set_profile(0)
+    prof = (5 * __import__("ctypes").c_double)()
+    lib.bmpc_ik_last_profile(prof)
+    kern = dict(zip(("ik_state_kernel", "ik_calcdiff_kernel", "ik_backward_kernel", "ik_forward_kernel", "other"), [float(v) for v in prof]))
     r = kb.results()
+    tele = D.reduce([r["ik_iters"].sum(), (r["ik_status"] != 0).sum(), (r["stats"][:, 5] != 0).sum()], "SUM")
+    it_max = D.reduce([r["ik_iters"].max()], "MAX")[0]
     # n_streams batches in flight on as many HIP streams, one host thread each (bunmpc_amd/pipeline.py): the tail
     # iterations of one batch -- a few stragglers, most of the chip idle -- overlap the bulk phases of the others.
     # Whole-job throughput of a generator that keeps several batches going.
     from bunmpc_amd.pipeline import StreamPool
     kbs = [kb] + [KinoDynDeviceBatch(wb, model, device=dev, num_iters=admm_iters, maxit=maxit) for _ in range(n_streams - 1)]
-    for k in kbs[1:]:
-        k.solve()
-    torch.cuda.synchronize(dev)
     if n_streams not in _POOLS:    # one pool per run: HIP spreads streams over a few hardware queues, and new streams per
         _POOLS[n_streams] = StreamPool(dev, n_streams)       # leg can land on one queue and serialise
-    t3 = time.perf_counter()
-    _POOLS[n_streams].run([k.solve for _ in range(steps) for k in kbs])
-    torch.cuda.synchronize(dev)
-    dt2 = (time.perf_counter() - t3) / steps
+    pool = _POOLS[n_streams]
+    dt2 = D.timed(lambda: pool.run([k.solve for k in kbs]), steps, 1) / steps
     same = True
     for k in kbs[1:]:
         r2 = k.results()
         same = same and bool(np.array_equal(r2["xs"], r["xs"]) and np.array_equal(r2["ik_iters"], r["ik_iters"]))
     del kbs
+    W = D.world
+    T, H = wb.ik_T, wb.dyn.H
+    abytes = (bb.algorithmic_bytes_per_solve(H, 4) + ik_algorithmic_bytes(T)) * B
+    dom = max(("ik_calcdiff_kernel", "ik_backward_kernel", "ik_forward_kernel"), key=lambda k: kern[k])
+    wkey = "kinodyn %s H=%d H_ik=%d B=%d admm_iters=%d" % (config, H, T, B, admm_iters)
+    out = {"value": W * B / dt, "unit": "KinoDynMP solves/s", "workload": "%s H=%d H_ik=%d B=%d/GPU" % (config, H, T, B),
+           "n_gpus": W, "batch": B, "global_batch": B * W, "ms_per_step": dt * 1e3, "steps": steps,
+           "multi_stream": {"streams": n_streams, "value": W * n_streams * B / dt2, "unit": "KinoDynMP solves/s",
+                            "ms_per_round_of_batches": dt2 * 1e3, "results_equal_single_stream": same},
+           "ik_only_ms_per_step": dt_ik * 1e3, "ik_kernel_ms_per_solve": kern,
+           "ddp_iters_mean": tele[0] / (B * W), "ddp_iters_max": int(it_max), "ddp_not_converged": int(tele[1]),
+           "admm_diverged": int(tele[2]),
+           "parity": "unpinned (crocoddyl 1.9.0 / pinocchio 2.6.9 absent): GPU vs two CPU restatements, tests/test_ik_gpu.py, "
+                     "tests/test_parity_envelope_gpu.py",
+           # HBM view of the whole solve (every kernel of one KinoDynMP.optimize batch): SURVEY 8d's per-solve bytes x B over the
+           # wall time of a solve; `dominant_kernel` the same bytes' IK share over that kernel's summed launches.  The path is
+           # latency / issue bound (DESIGN.md 9), so the fraction is tiny by construction.
+           "roofline": {"bound": "hbm", "achieved": abytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": abytes / dt / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(wkey),
+                        "scope": "all kernels of one batch solve", "algorithmic_bytes_per_solve_batch": abytes,
+                        "dominant_kernel": {"kernel": dom, "ms_per_solve_batch": kern[dom],
+                                            "achieved": ik_algorithmic_bytes(T) * B / (kern[dom] * 1e-3) / 1e9 if kern[dom] > 0 else None,
+                                            "algorithmic_bytes": ik_algorithmic_bytes(T) * B}}}
     # the inputs of the same batch built on the device from the raw states (bmpc_wb_plan_batch_device)
-    plan_ms = None
     if config == "solo12_h20":
         from bunmpc_amd import fk_np
         from bunmpc_amd.inverse_kinematics_cpp import as_device_model
@@ -177,21 +306,14 @@ def kinodyn_leg(dev, B, admm_iters, maxit, config="solo12_h20", steps=3, n_strea
         offs[:, 1] += np.array([0.04, -0.04, 0.04, -0.04])
         p = DeviceWbPlan(as_device_model(model), problems.TROT, offs[:, :2], problems.FEET, problems.TROT_IK, wb.x, wb.dyn.meta["t0"],
                          wb.dyn.meta["v_des_body"], wb.dyn.H, wb.ik_T, device=dev)
-        p.build()
-        torch.cuda.synchronize(dev)
-        t2 = time.perf_counter()
-        for _ in range(10):
-            p.build()
-        torch.cuda.synchronize(dev)
-        plan_ms = (time.perf_counter() - t2) / 10 * 1e3
-    return {"value": B / dt, "unit": "KinoDynMP solves/s", "workload": "%s H=%d H_ik=%d" % (config, wb.dyn.H, wb.ik_T),
-            "device_built_inputs_ms": plan_ms,
-            "batch": B, "ms_per_step": dt * 1e3,
-            "multi_stream": {"streams": n_streams, "value": n_streams * B / dt2, "unit": "KinoDynMP solves/s",
-                             "ms_per_round_of_batches": dt2 * 1e3, "results_equal_single_stream": same},
-            "ik_only_ms_per_step": dt_ik * 1e3, "ddp_iters_mean": float(r["ik_iters"].mean()),
-            "ddp_iters_max": int(r["ik_iters"].max()), "ddp_not_converged": int((r["ik_status"] != 0).sum()),
-            "admm_diverged": int((r["stats"][:, 5] != 0).sum())}
+        out["device_built_inputs_ms"] = D.timed(p.build, 10, 1) / 10 * 1e3
+    if cpu_sample and D.world == 1:
+        try:
+            out["cpu_baseline"] = kinodyn_cpu_baseline(model, wb, admm_iters, maxit, cpu_sample)
+            out["speedup_vs_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["value"]
+        except Exception as e:       # noqa: BLE001 -- the GPU measurement above must not be lost with it
+            out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
 
 
 def datagen_leg(dev, B, admm_iters):
@@ -244,13 +366,83 @@ def datagen_leg(dev, B, admm_iters):
             "id_frac_of_hbm_peak": id_bytes / id_ms / 1e6 / 8000.0}
 
 
+def biconvex_leg(D, args):
+    """the headline: one launch of biconvex_admm_kernel over B problems per GPU per step"""
+    import torch
+    from bunmpc_amd import batch as bb
+    from bunmpc_amd import problems
+    B, dev = args.batch, D.dev
+    pb = problems.make_batch(args.config, B, first=D.rank * B)
+    db = bb.DeviceBatch(pb, device=dev, num_iters=args.admm_iters, maxit=args.maxit, precision=args.precision)
+    for _ in range(args.warmup):
+        db.solve()
+    D.sync()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        ev[s][0].record()
+        db.solve()
+        ev[s][1].record()
+    D.sync()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    res = db.results()
+    elapsed, kern_ms = D.reduce([elapsed, kern_ms], "MAX")
+    counts = D.reduce([(res["stats"][:, 5] != 0).sum(), res["stats"][:, 1:3].sum(), flops_from_stats(res["stats"], pb.H)], "SUM")
+    W = D.world
+    total = B * W * args.steps
+    per_w = pb.W_X.shape[0] != 1
+    abytes = bb.algorithmic_bytes_per_solve(pb.H, pb.E, per_w) * B
+    achieved = abytes / (kern_ms * 1e-3) / 1e9
+    flops = counts[2] / W  # per launch on one GPU
+    wkey = "%s H=%d B=%d admm_iters=%d fista_maxit=%d %s" % (args.config, pb.H, B, args.admm_iters, args.maxit, args.precision)
+    prec = {"f64": "fp64", "f32": "fp32 iterates, fp64 decisions"}[args.precision]
+    out = {
+        "metric": "MPC solves/sec (batch, whole node), %s, %d ADMM iters, %s" % (METRIC_SHAPE.get(args.config, args.config), args.admm_iters, prec),
+        "value": total / elapsed, "unit": "solves/s", "n_gpus": W, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+        "data": "synthetic",
+        "config": {"workload": "%s H=%d B=%d/GPU admm_iters=%d fista_maxit=%d cold-start"
+                               % (args.config, pb.H, B, args.admm_iters, args.maxit),
+                   "global_batch": B * W, "parallelism": "batch-shard x%d" % W},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(wkey),
+                     "kernel": "biconvex_admm_kernel<%s>" % ("double" if args.precision == "f64" else "float"), "kernel_ms": kern_ms,
+                     "algorithmic_bytes_per_launch": abytes,
+                     "valu": {"model_flops_per_launch": flops,
+                              "achieved_tflops": flops / (kern_ms * 1e-3) / 1e12,
+                              "peak_tflops": FP64_VALU_PEAK_TF,
+                              "frac": flops / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF}},
+        "diverged": int(counts[0]), "fista_iters_per_solve": counts[1] / (B * W),
+    }
+    if args.config == "go2_bound":
+        out["note"] = "synthetic Go2 runs with mu = 10, not the reference's fixed mu = 1 (the reference algorithm NaNs for a 15 kg robot at mu = 1: tests/test_oracle_cpu.py)"
+    return out, pb
+
+
+def fp32_parity_note(pb, args):
+    """config 3's residual check in the line: the fp32 kernel against the CPU oracle on a sample of the batch"""
+    from bunmpc_amd import batch as bb
+    from oracle import oracle_c
+    sub = pb.take(np.arange(0, pb.B, max(1, pb.B // 64))[:64])
+    ref = oracle_c.solve_batch(sub, num_iters=args.admm_iters, maxit=args.maxit)
+    got = bb.solve_host(sub, num_iters=args.admm_iters, maxit=args.maxit, precision="f32")
+    e = np.maximum(np.linalg.norm(got["X"] - ref["X"], axis=1) / np.linalg.norm(ref["X"], axis=1),
+                   np.linalg.norm(got["F"] - ref["F"], axis=1) / np.linalg.norm(ref["F"], axis=1))
+    return {"sample": int(sub.B), "rel_l2_vs_cpu_oracle_median": float(np.median(e)), "rel_l2_vs_cpu_oracle_max": float(e.max()),
+            "same_admm_count": bool(np.array_equal(got["stats"][:, 0], ref["stats"][:, 0]))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="biconvex", choices=["biconvex", "kinodyn"],
+                    help="what the JSON line's metric / value measure: the centroidal batch solve (headline) or the full KinoDynMP.optimize")
     ap.add_argument("--batch", type=int, default=4096, help="problems per GPU")
-    ap.add_argument("--config", default="solo12_trot")
+    ap.add_argument("--config", default="solo12_trot", help="solo12_trot (headline) | solo12_mixed (BASELINE config 4) | go2_bound (config 3)")
     ap.add_argument("--admm-iters", type=int, default=10)
     ap.add_argument("--maxit", type=int, default=150)
     ap.add_argument("--cpu-sample", type=int, default=4096)
@@ -259,7 +451,8 @@ def main():
     ap.add_argument("--no-kinodyn", action="store_true")
     ap.add_argument("--kinodyn-main-only", action="store_true", help="skip the Go2 H=60 and data-path legs (counter collection)")
     ap.add_argument("--kinodyn-streams", type=int, default=3, help="batches in flight in the multi-stream KinoDyn measurement")
-    ap.add_argument("--kinodyn-batch", type=int, default=4096)
+    ap.add_argument("--kinodyn-batch", type=int, default=0, help="problems per GPU of the KinoDyn leg (default 4096; 1024 for go2_h60)")
+    ap.add_argument("--kinodyn-steps", type=int, default=3)
     ap.add_argument("--kinodyn-config", default="solo12_h20", choices=["solo12_h20", "go2_h60"],
                     help="solo12_h20: Solo12 trot H=20 / H_ik=10; go2_h60: BASELINE config 5 (synthetic Go2, H=60 / H_ik=30)")
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"],
@@ -287,100 +480,75 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
     if args.gpus != world and rank == 0:
         print("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    D = Dist(torch, dist, dev, world, rank, rehearsal)
+    cpu_ok = world == 1 and not args.no_cpu
+    if cpu_ok:
+        build_oracles()
+    kd_batch = lambda cfg: args.kinodyn_batch or (1024 if cfg == "go2_h60" else 4096)      # noqa: E731
+    kd_sample = lambda cfg: 0 if not cpu_ok else (256 if cfg == "go2_h60" else 2048)      # noqa: E731
 
-    from bunmpc_amd import batch as bb
-    from bunmpc_amd import problems
-    B = args.batch
-    pb = problems.make_batch(args.config, B, first=rank * B)
-    db = bb.DeviceBatch(pb, device=dev, num_iters=args.admm_iters, maxit=args.maxit, precision=args.precision)
+    def guarded(fn):
+        """a failing secondary leg is reported in the line (never hidden, never allowed to lose the measurement already
+        made); every rank takes part in every leg, so a leg's collectives stay matched"""
+        try:
+            return fn()
+        except Exception as e:       # noqa: BLE001 -- recorded in the output
+            return {"error": "%s: %s" % (type(e).__name__, e)}
 
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        db.solve()
-    sync()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        ev[s][0].record()
-        db.solve()
-        ev[s][1].record()
-    sync()
-    elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    res = db.results()
-    tele = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
-    counts = torch.tensor([float((res["stats"][:, 5] != 0).sum()), float(res["stats"][:, 1:3].sum()),
-                           flops_from_stats(res["stats"], pb.H)], dtype=torch.float64, device=dev)
-    if world > 1:
-        if rehearsal:
-            tele, counts = tele.cpu(), counts.cpu()
-        dist.all_reduce(tele, op=dist.ReduceOp.MAX)
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-    elapsed, kern_ms = float(tele[0]), float(tele[1])
-    total = B * world * args.steps
-
-    if rank == 0:
-        per_w = pb.W_X.shape[0] != 1
-        abytes = bb.algorithmic_bytes_per_solve(pb.H, pb.E, per_w) * B
-        achieved = abytes / (kern_ms * 1e-3) / 1e9
-        flops = float(counts[2]) / world  # per launch on one GPU
-        wkey = "%s H=%d B=%d admm_iters=%d fista_maxit=%d %s" % (args.config, pb.H, B, args.admm_iters, args.maxit, args.precision)
-        traffic = pmc_traffic(wkey)
-        out = {
-            "metric": "MPC solves/sec (batch, whole node), Solo12 trot H=20, 10 ADMM iters, fp64",
-            "value": total / elapsed, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
-            "data": "synthetic",
-            "config": {"workload": "%s H=%d B=%d/GPU admm_iters=%d fista_maxit=%d cold-start"
-                                   % (args.config, pb.H, B, args.admm_iters, args.maxit),
-                       "global_batch": B * world, "parallelism": "batch-shard x%d" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "biconvex_admm_kernel", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": abytes,
-                         "valu": {"model_flops_per_launch": flops,
-                                  "achieved_tflops": flops / (kern_ms * 1e-3) / 1e12,
-                                  "peak_tflops": FP64_VALU_PEAK_TF,
-                                  "frac": flops / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF}},
-            "diverged": int(counts[0]), "fista_iters_per_solve": float(counts[1]) / (B * world),
-        }
-        if world == 1 and not args.no_cpu:
+    if args.workload == "kinodyn":
+        cfg = args.kinodyn_config
+        leg = kinodyn_leg(D, kd_batch(cfg), args.admm_iters, args.maxit, cfg, steps=args.steps, warmup=args.warmup,
+                          n_streams=args.kinodyn_streams, cpu_sample=kd_sample(cfg))
+        shape = "Go2 trot H=60 with full IK-DDP inner loop (H_ik=30)" if cfg == "go2_h60" else "Solo12 trot H=20 with full IK-DDP (H_ik=10)"
+        out = {"metric": "KinoDynMP solves/sec (batch, whole node), %s, %d ADMM iters, fp64" % (shape, args.admm_iters),
+               "value": leg["value"], "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": leg["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic",
+               "config": {"workload": "kinodyn %s admm_iters=%d fista_maxit=%d ddp_maxiter=100 cold-start" % (leg["workload"], args.admm_iters, args.maxit),
+                          "global_batch": leg["global_batch"], "parallelism": "batch-shard x%d" % world},
+               "roofline": leg.pop("roofline")}
+        if "cpu_baseline" in leg:
+            out["cpu_baseline"] = leg.pop("cpu_baseline")
+            out["speedup_vs_cpu_all_cores"] = leg.pop("speedup_vs_cpu_all_cores", None)
+        out["details"] = leg
+    else:
+        out, pb = biconvex_leg(D, args)
+        if cpu_ok:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.config, args.admm_iters, args.cpu_sample, args.maxit)
                 out["speedup_vs_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["value"]
                 out["speedup_vs_matrix_free_cpu"] = out["value"] / out["cpu_baseline"]["matrix_free_variant"]["value"]
             except Exception as e:       # noqa: BLE001 -- the GPU measurement above must not be lost with it
                 out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        # The legs below are informational: the headline line above is complete without them, and a failure in one of them
-        # is reported in the line (never hidden, never allowed to lose the measurement already made).
-        def informational(key, fn):
-            try:
-                out[key] = fn()
-            except Exception as e:       # noqa: BLE001 -- recorded in the output
-                out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+            if args.precision == "f32":
+                out["fp32_residual_check"] = guarded(lambda: fp32_parity_note(pb, args))
 
         def host_leg():
             # the same batch through the host-buffer entry point (pageable numpy arrays in, H2D, one launch, D2H):
             # the PCIe-inclusive rate -- reported beside `value`, never as it
+            from bunmpc_amd import batch as bb
             bb.solve_host(pb, num_iters=args.admm_iters, maxit=args.maxit, precision=args.precision)
             th = time.perf_counter()
             for _ in range(3):
                 bb.solve_host(pb, num_iters=args.admm_iters, maxit=args.maxit, precision=args.precision)
-            return 3 * B / (time.perf_counter() - th)
+            return 3 * pb.B / (time.perf_counter() - th)
         if world == 1 and not args.no_latency:
-            informational("p50_latency_ms_batch1", lambda: p50_latency(args.config, args.admm_iters))
-            informational("host_buffers_solves_per_s", host_leg)
-        if world == 1 and not args.no_kinodyn:
-            informational("kinodyn_full_solve", lambda: kinodyn_leg(dev, args.kinodyn_batch, args.admm_iters, args.maxit, args.kinodyn_config,
-                                                                    n_streams=args.kinodyn_streams))
-            if args.kinodyn_config == "solo12_h20" and not args.kinodyn_main_only:   # BASELINE config 5's shape as well (1024 problems = its per-GPU share)
-                informational("kinodyn_go2_h60", lambda: kinodyn_leg(dev, 1024, args.admm_iters, args.maxit, "go2_h60", n_streams=args.kinodyn_streams))
-                informational("datagen_pass", lambda: datagen_leg(dev, args.kinodyn_batch, args.admm_iters))
+            lat = guarded(lambda: p50_latency(args.config, args.admm_iters))
+            out["p50_latency_ms_batch1"] = lat.get("p50_ms", lat)
+            out["latency_batch1"] = lat
+            out["latency_kinodyn_dropin"] = guarded(kinodyn_latency)
+            out["host_buffers_solves_per_s"] = guarded(host_leg)
+        if not args.no_kinodyn:
+            cfg = args.kinodyn_config
+            out["kinodyn_full_solve"] = guarded(lambda: kinodyn_leg(D, kd_batch(cfg), args.admm_iters, args.maxit, cfg, steps=args.kinodyn_steps,
+                                                                     n_streams=args.kinodyn_streams, cpu_sample=kd_sample(cfg)))
+            if cfg == "solo12_h20" and not args.kinodyn_main_only:   # BASELINE config 5's shape as well (1024 problems = its per-GPU share)
+                out["kinodyn_go2_h60"] = guarded(lambda: kinodyn_leg(D, kd_batch("go2_h60"), args.admm_iters, args.maxit, "go2_h60",
+                                                                      steps=args.kinodyn_steps, n_streams=args.kinodyn_streams,
+                                                                      cpu_sample=kd_sample("go2_h60")))
+                if world == 1:
+                    out["datagen_pass"] = guarded(lambda: datagen_leg(dev, kd_batch(cfg), args.admm_iters))
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

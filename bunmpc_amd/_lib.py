@@ -170,6 +170,9 @@ _SIGS = {
     "bmpc_ik_last_stats": (_I, [_P, _P, _P, _P, _P]),
     "bmpc_ik_workspace_doubles": (_I, [_I]),
     "bmpc_ik_layout": (None, [_I, _P]),
+    "bmpc_ik_layout_trace": (None, [_I, _P, _P, _P]),
+    "bmpc_ik_set_profile": (_I, [_I]),
+    "bmpc_ik_last_profile": (None, [_P]),
     "bmpc_ik_solve_batch_device": (_I, [_P, _P]),
     "bmpc_ik_centroidal_state_device": (_I, [_P, _P, _P, _I, _P]),
     "bmpc_kinodyn_create": (_P, [_P, _D, _I, _I, _I]),

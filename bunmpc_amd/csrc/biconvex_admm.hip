@@ -182,9 +182,10 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
 
     const R dt = ldz<R>(a.dt, pb * H + t, rvalid);
     const R dtp = from_prev(dt);  // dt of knot t-1 (0 for t == 0: previous lane is a dead/terminal lane)
-    const bool cold = a.cold_start != 0;
-    R L_x = (R)(cold ? a.L0_x : (pvalid ? a.L_x[pb] : 1.0));
-    R L_f = (R)(cold ? a.L0_f : (pvalid ? a.L_f[pb] : 1.0));
+    const bool cold = a.cold_start != 0;      // 1: fresh solver object (iterates and step constants reset); 2: iterates only --
+    const bool fresh_L = a.cold_start == 1;   // FISTA's L_ is set in the constructor and survives every optimize call (fista.hpp:52)
+    R L_x = (R)(fresh_L ? a.L0_x : (pvalid ? a.L_x[pb] : 1.0));
+    R L_f = (R)(fresh_L ? a.L0_f : (pvalid ? a.L_f[pb] : 1.0));
     if (cold) {  // KinoDynMP::set_warm_starts (kino_dyn.cpp:83-99): X = tile(x_init), F = 0, P = 0
         if (kvalid) { UNROLL for (int l = 0; l < 9; ++l) Xg[l] = (R)a.x_init[pb * 9 + l]; }
         if (rvalid) {

@@ -49,7 +49,7 @@ struct BatchArgs {
 };
 
 constexpr int kStats = 6;
-constexpr int kMaxFistaIters = 8192;  // momentum table lives in LDS (8 B per iteration)
+constexpr int kMaxFistaIters = 4096;  // momentum table lives in LDS (8 B per iteration): 32 KB + <= 30 KB of iterates < 64 KB
 constexpr int kMaxKnots = 64;  // H + 1 <= 64: one knot per lane, one problem per <=64 lanes
 
 // Launch the batched ADMM kernel on `stream`.  Returns hipSuccess or the launch error;

@@ -72,7 +72,8 @@ int check_batch(const bmpc_batch_t *d) {
     if (d->n_col + 1 > bunmpc::kMaxKnots)
         return fail(BMPC_BAD_ARG, "n_col + 1 > 64 knots is not supported by the one-knot-per-lane kernel");
     if (d->num_iters < 0 || d->maxit < 0) return fail(BMPC_BAD_ARG, "negative iteration cap");
-    if (d->maxit > bunmpc::kMaxFistaIters) return fail(BMPC_BAD_ARG, "maxit > 8192 is not supported");
+    if (d->maxit > bunmpc::kMaxFistaIters) return fail(BMPC_BAD_ARG, "maxit > 4096 is not supported");
+    if (d->cold_start < 0 || d->cold_start > 2) return fail(BMPC_BAD_ARG, "cold_start must be 0, 1 or 2");
     if (d->precision != 0 && d->precision != 1) return fail(BMPC_BAD_ARG, "precision must be 0 (fp64) or 1 (fp32)");
     if (d->precision == 1 && d->raw) return fail(BMPC_BAD_ARG, "fp32 arithmetic is built for the harness form only");
     if (!d->cnt_plan || !d->dt || !d->x_init || !d->X || !d->F || !d->P || !d->L_x || !d->L_f)

@@ -16,6 +16,7 @@ int launch_wb_plan(const RobotModelDev *model, const bmpc_wb_plan_batch_t &d, hi
 #include <iostream>
 #include <map>
 #include <mutex>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -156,10 +157,14 @@ bunmpc::IkBatchArgs make_args(int B, int T, int maxiter, const bmpc_model *model
 int g_spec_line_search_below = 1024;
 constexpr int kMaxIkCol = 63;     // T + 1 <= 64 nodes: the backward pass computes the gaps one lane per node
 
-// two host-mapped words and events per host thread, through which the kernels' active counter reaches the DDP loop
+// Two host-mapped words and events per (device, stream), through which the kernels' active counter reaches the DDP loop.
+// Keyed by the stream, not by the host thread: a stream's publishes are ordered among themselves, so a late publish of one
+// batch can never overwrite the counter of another batch running on a different stream; and the few entries (one per stream
+// ever used) live as long as the library, whatever threads come and go (bunmpc_amd/pipeline.py starts workers per call).
 struct ActiveWord {
     int *host[2] = {nullptr, nullptr}, *dev[2] = {nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};
+    std::mutex in_use;      // one DDP loop at a time per stream (two host threads driving one stream would interleave anyway)
     int ensure() {
         if (host[0]) return BMPC_OK;
         for (int k = 0; k < 2; ++k) {
@@ -170,12 +175,43 @@ struct ActiveWord {
         return BMPC_OK;
     }
 };
-thread_local ActiveWord g_active_word;
+std::mutex g_active_words_lock;
+std::map<std::pair<int, hipStream_t>, ActiveWord *> &active_words() {
+    static auto *m = new std::map<std::pair<int, hipStream_t>, ActiveWord *>;   // never destroyed: the HIP runtime may be gone at exit
+    return *m;
+}
+ActiveWord *active_word_for(hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> hold(g_active_words_lock);
+    ActiveWord *&w = active_words()[{dev, st}];
+    if (!w) w = new ActiveWord;
+    return w;
+}
+
+// bmpc_ik_set_profile(1): hipEvents around every kernel of the DDP loop; the summed times per kernel of the last batch
+// solve are read back with bmpc_ik_last_profile.  For measurement passes only (the events cost launch slots).
+bool g_profile = false;
+double g_last_profile[5] = {0, 0, 0, 0, 0};     // ms: state, calcdiff, backward, forward, everything else in the loop
+std::mutex g_profile_lock;
 
 int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run) {
     bunmpc::IkBatchArgs a = a0;
     a.fwd_spec = 0;
-    ActiveWord &w = g_active_word;
+    const bool prof = g_profile;
+    std::vector<hipEvent_t> pev;
+    auto stamp = [&]() -> int {
+        if (!prof) return BMPC_OK;
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipEventRecord(e, st));
+        pev.push_back(e);
+        return BMPC_OK;
+    };
+    ActiveWord *wp = active_word_for(st);
+    if (!wp) return ik_fail(BMPC_DEVICE_ERROR, "hipGetDevice failed");
+    ActiveWord &w = *wp;
+    std::lock_guard<std::mutex> hold(w.in_use);
     if (int rc = w.ensure()) return rc;
     HIP_TRY(bunmpc::ik_launch_init(a, st));
     // The host looks at the active counter after every iteration while many problems are iterating (iterations are long
@@ -184,21 +220,27 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run) {
     // one chunk late: the next chunk is enqueued BEFORE the host waits for the counter of the one before, so the queue
     // never drains while the host turns around (at the end one chunk of no-op kernels runs out on its own).
     constexpr int kTailChunk = 3;
-    int active = a.B, it = 0;
+    int active = a.B, it = 0, it_end[2] = {0, 0};
     auto enqueue_chunk = [&](int slot) -> int {
         const int chunk = active <= g_spec_line_search_below ? kTailChunk : 1;
         a.fwd_spec = active <= g_spec_line_search_below / 3 ? 3 : active <= g_spec_line_search_below ? 2 : 0;
         for (int k = 0; k < chunk && it < a.maxiter; ++k, ++it) {
+            if (int rc = stamp()) return rc;
             HIP_TRY(bunmpc::ik_launch_state(a, st));
+            if (int rc = stamp()) return rc;
             HIP_TRY(bunmpc::ik_launch_calcdiff(a, st));
+            if (int rc = stamp()) return rc;
             HIP_TRY(bunmpc::ik_launch_backward(a, st));
+            if (int rc = stamp()) return rc;
             HIP_TRY(bunmpc::ik_launch_forward(a, st));
+            if (int rc = stamp()) return rc;
         }
         HIP_TRY(bunmpc::ik_launch_publish_active(a.active, w.dev[slot], st));
         HIP_TRY(hipEventRecord(w.ev[slot], st));
+        it_end[slot] = it;
         return BMPC_OK;
     };
-    int slot = 0;
+    int slot = 0, it_done = 0;
     if (a.maxiter > 0 && active > 0) {
         if (int rc = enqueue_chunk(slot)) return rc;
         for (;;) {
@@ -206,11 +248,29 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run) {
             if (more) { if (int rc = enqueue_chunk(slot ^ 1)) return rc; }
             HIP_TRY(hipEventSynchronize(w.ev[slot]));
             active = *static_cast<volatile int *>(w.host[slot]);
-            if (active <= 0 || !more) break;
+            it_done = it_end[slot];
+            if (active <= 0 || !more) {
+                // the chunk enqueued ahead (no-op kernels and one more publish into the other word) must have drained before
+                // this stream's words can serve another batch
+                if (more) HIP_TRY(hipEventSynchronize(w.ev[slot ^ 1]));
+                break;
+            }
             slot ^= 1;
         }
     }
-    if (iters_run) *iters_run = it;
+    if (iters_run) *iters_run = it_done;     // iterations up to the look that found every problem done (not the chunk enqueued ahead)
+    if (prof && !pev.empty()) {
+        HIP_TRY(hipEventSynchronize(pev.back()));
+        double acc[5] = {0, 0, 0, 0, 0};
+        for (size_t i = 0; i + 1 < pev.size(); ++i) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, pev[i], pev[i + 1]));
+            acc[i % 5 < 4 ? i % 5 : 4] += ms;     // five stamps per iteration: the fifth interval is the gap to the next iteration
+        }
+        for (hipEvent_t e : pev) (void)hipEventDestroy(e);
+        std::lock_guard<std::mutex> hold(g_profile_lock);
+        for (int k = 0; k < 5; ++k) g_last_profile[k] = acc[k];
+    }
     return BMPC_OK;
 }
 
@@ -339,6 +399,11 @@ int bmpc_perturb_batch_device(const bmpc_perturb_batch_t *d, void *hip_stream) {
     return launch_perturb(a, static_cast<hipStream_t>(hip_stream));
 }
 
+int bmpc_ik_set_profile(int on) { const int old = g_profile; g_profile = on != 0; return old; }
+void bmpc_ik_last_profile(double *ms5) {
+    std::lock_guard<std::mutex> hold(g_profile_lock);
+    for (int k = 0; k < 5; ++k) ms5[k] = g_last_profile[k];
+}
 int bmpc_ik_set_speculative_below(int n_active) { const int old = g_spec_line_search_below; g_spec_line_search_below = n_active; return old; }
 double bmpc_model_total_mass(const bmpc_model_t *m) { return m ? m->host.total_mass : 0.0; }
 
@@ -566,6 +631,13 @@ void bmpc_ik_layout(int n_col, long *offsets8) {   // xs, us, scal, K, kff, fs, 
     const bunmpc::IkLayout L = bunmpc::IkLayout::make(n_col);
     offsets8[0] = L.xs; offsets8[1] = L.us; offsets8[2] = L.scal; offsets8[3] = L.K; offsets8[4] = L.kff;
     offsets8[5] = L.fs; offsets8[6] = L.Lx; offsets8[7] = L.Lxx;
+}
+
+void bmpc_ik_layout_trace(int n_col, long *offset, int *iters, int *width) {   // the per-iteration telemetry rows of a problem's workspace
+    const bunmpc::IkLayout L = bunmpc::IkLayout::make(n_col);
+    if (offset) *offset = L.trace;
+    if (iters) *iters = bunmpc::kTraceIters;
+    if (width) *width = bunmpc::kTraceDoubles;
 }
 
 // batch of KinoDynMP::optimize calls, device resident: centroidal state of (q, v) -> ADMM (cold start)

@@ -1114,6 +1114,10 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
         if (accepted) { sc[S_WASFEAS] = feas ? 1.0 : 0.0; sc[S_FEAS] = 1.0; sc[S_COST] = cost_try; sc[S_RECALC] = 1.0; }
         else sc[S_RECALC] = 0.0;
         sc[S_XREG] = xreg; sc[S_ITERS] = iters;
+        if (iters <= (double)kTraceIters) {
+            double *tr = ws + L.trace + ((long)iters - 1) * kTraceDoubles;
+            tr[0] = accepted ? cost_try : cost; tr[1] = xreg; tr[2] = accepted ? alpha : 0.0; tr[3] = sc[S_STOP];
+        }
         if (done) { sc[S_DONE] = 1.0; sc[S_STATUS] = status; atomicSub(a.active, 1); }
     }
 }

@@ -41,11 +41,14 @@ constexpr int kNodeTaskDoubles = 5 * kFrameSlots + 4 + 7 + 2;
 // trial trajectories per problem: slot 0 is the one the sequential line search uses; the speculative line search
 // (four step lengths of one problem at once, ik_forward_kernel) fills all four
 constexpr int kTrySlots = 4;
+// per-iteration trace of a problem's DDP (telemetry, read back by the parity tests): after iteration i (0-based, i < kTraceIters)
+// [cost, regularisation, accepted step length (0 = none), stopping criterion] as SolverDDP holds them at the end of the iteration
+constexpr int kTraceIters = 128, kTraceDoubles = 4;
 
 // Layout of the per-problem DDP workspace in HBM (doubles), T = number of running nodes.
 struct IkLayout {
     int T;
-    long xs, us, xs_try, us_try, fs, xnext, Lx, Lxx, Lu, Luu, A6, B6, K, kff, Qu, Quuk, scal, nrs, njl, ncs, total;
+    long xs, us, xs_try, us_try, fs, xnext, Lx, Lxx, Lu, Luu, A6, B6, K, kff, Qu, Quuk, scal, nrs, njl, ncs, trace, total;
     __host__ __device__ static IkLayout make(int T) {
         IkLayout l; l.T = T;
         long o = 0;
@@ -61,6 +64,7 @@ struct IkLayout {
         l.scal = take(16);
         // per node, written by ik_state_kernel for ik_calcdiff_kernel (bulk iterations): state residual, its Jlog6 block, cost part
         l.nrs = take((long)(T + 1) * kNDX); l.njl = take((long)(T + 1) * 36); l.ncs = take((long)T + 1);
+        l.trace = take((long)kTraceIters * kTraceDoubles);
         l.total = o;
         return l;
     }

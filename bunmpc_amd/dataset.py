@@ -4,10 +4,14 @@
 
 h5py is not part of this image, so `save()` writes the same four arrays to `database_<iter>.npz` unless h5py imports;
 `tools/npz_to_hdf5.py` turns such a file into the reference's HDF5 on a machine that has h5py.  The reference also pickles
-its hydra config next to the data (`config.pkl`); a config is a plain dict here and is written as JSON.
+its hydra config next to the data, once (`config.pkl` = `pickle.dump(OmegaConf.to_container(cfg, resolve=True))`,
+`data_collection.py:116-122`: a plain dict of builtins): written here the same way with the standard library's pickle, plus a
+human-readable `config.json` beside it.  A hand-rolled HDF5 container stays unbuilt: nothing in this image can read one back,
+so it could not be checked.
 """
 import json
 import os
+import pickle
 
 import numpy as np
 
@@ -65,11 +69,28 @@ class Database:
             with h5py.File(path, "w") as hf:
                 for k, v in arrs.items():
                     hf.create_dataset(k, data=v)
-        cfg = os.path.join(directory, "config.json")
-        if config is not None and not os.path.exists(cfg):
-            with open(cfg, "w") as f:
+        pkl = os.path.join(directory, "config.pkl")
+        if config is not None and not os.path.exists(pkl):       # "save config as pickle only once" (data_collection.py:115-122)
+            with open(pkl, "wb") as f:
+                pickle.dump(_plain(config), f)
+            with open(os.path.join(directory, "config.json"), "w") as f:
                 json.dump(config, f, indent=1, default=str)
         return path
+
+
+def _plain(x):
+    """what OmegaConf.to_container leaves behind: dicts / lists / builtin scalars only"""
+    if isinstance(x, dict):
+        return {str(k): _plain(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_plain(v) for v in x]
+    if isinstance(x, np.generic):
+        return x.item()
+    if isinstance(x, np.ndarray):
+        return x.tolist()
+    if x is None or isinstance(x, (bool, int, float, str)):
+        return x
+    return str(x)
 
 
 def vc_goal_rows(t, gait_period, v_des, w_des, gait_name):

@@ -35,6 +35,9 @@ class KinoDynDeviceBatch:
         off = (C.c_long * 8)()
         lib.bmpc_ik_layout(T, off)
         self.off = dict(zip(("xs", "us", "scal", "K", "k", "fs", "Lx", "Lxx"), list(off)))
+        t_off, t_it, t_w = C.c_long(0), C.c_int(0), C.c_int(0)
+        lib.bmpc_ik_layout_trace(T, C.byref(t_off), C.byref(t_it), C.byref(t_w))
+        self.trace_off, self.trace_iters, self.trace_width = t_off.value, t_it.value, t_w.value
         self.ws = torch.zeros((B, self.ws_doubles), dtype=f64, device=self.device)
         self.active = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.iters_run = C.c_int(0)
@@ -72,4 +75,6 @@ class KinoDynDeviceBatch:
         out["ik_cost"], out["ik_stop"] = sc[:, 0], sc[:, 4]
         out["ik_iters"], out["ik_status"] = sc[:, 8].astype(np.int64), sc[:, 10].astype(np.int64)
         out["ddp_loop_iters"] = self.iters_run.value
+        # rows [iteration][cost, regularisation, accepted step length (0 = none), |Q_u|^2]; rows past ik_iters are stale
+        out["ik_trace"] = ws[:, self.trace_off:self.trace_off + self.trace_iters * self.trace_width].reshape(-1, self.trace_iters, self.trace_width)
         return out

@@ -363,6 +363,12 @@ class WholeBodyBatch:
     wt_mom: float
     frame_ids: tuple
 
+    def take(self, idx):
+        """sub-batch of the problems listed in idx (copies)"""
+        idx = np.asarray(idx)
+        return WholeBodyBatch(self.dyn.take(idx), self.x[idx].copy(), self.ik_T, self.ik_tasks[idx].copy(), self.state_w, self.ctrl_w,
+                              self.x_reg[idx].copy(), self.wt_com, self.wt_mom, self.frame_ids)
+
 
 def _log3_batch(R):
     v = np.stack([R[:, 2, 1] - R[:, 1, 2], R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] - R[:, 0, 1]], axis=1)

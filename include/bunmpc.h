@@ -115,8 +115,12 @@ int bmpc_biconvex_set_robot_mass(bmpc_biconvex_t *h, double m);
 typedef struct {
     int B, n_col, n_eff, raw;
     int num_iters, maxit;
-    int cold_start;   /* 1: ignore X/F/P/L_x/L_f on entry and start as KinoDynMP::set_warm_starts does
-                         (kino_dyn.cpp:83-99): X = tile(x_init), F = 0, P = 0, L = BMPC_L0_X / BMPC_L0_F */
+    int cold_start;   /* 0: X/F/P/L_x/L_f on entry are the warm start (set_warm_start_vars; L_ persists, fista.hpp:52).
+                         1: a FRESH KinoDynMP per problem: ignore X/F/P/L_x/L_f on entry -- X = tile(x_init), F = 0, P = 0
+                            (KinoDynMP::set_warm_starts, kino_dyn.cpp:83-99) AND L = BMPC_L0_X / BMPC_L0_F (the constructor's
+                            values, biconvex.cpp:20-21): independent batch elements.
+                         2: the NEXT optimize call of the same KinoDynMP objects: iterates reset as in 1, L_x / L_f taken from
+                            the arrays (the reference never resets FISTA's L_ between calls): replans of the same rollouts. */
     int precision;    /* 0: fp64 arithmetic (reference behaviour).  1: fp32 iterates / operators / projections with
                          every accept / exit decision and the dynamics violation reduced in fp64; harness form
                          only; arrays stay fp64 in memory (BASELINE config 3) */
@@ -212,12 +216,20 @@ typedef struct {
     long s_x_reg, sn_state_w, sn_x_reg, sn_ctrl_w;   /* 0 = defaults: x_reg [B][37], one vector per problem */
 } bmpc_ik_batch_t;
 int bmpc_ik_workspace_doubles(int n_col);
-void bmpc_ik_layout(int n_col, long *offsets8);
+void bmpc_ik_layout(int n_col, long *offsets8);      /* xs, us, scalars, K, k, fs, Lx, Lxx */
+/* telemetry: rows [iteration i < *iters][*width = 4] at *offset of a problem's workspace: cost, regularisation, accepted step
+ * length (0 = none) and stopping criterion |Q_u|^2 as SolverDDP holds them at the end of iteration i */
+void bmpc_ik_layout_trace(int n_col, long *offset, int *iters, int *width);
 /* Line-search scheduling of the batched DDP (no effect on results): while at most n_active problems are still
  * iterating, four step lengths of a problem are tried side by side (one wave per problem) instead of one after the
  * other (four problems per wave).  Default 1024 (one wave per SIMD of an MI355X); 0 = never.  Returns the old value. */
-int bmpc_ik_set_speculative_below(int n_active);   /* xs, us, scalars, K, k, fs, Lx, Lxx */
+int bmpc_ik_set_speculative_below(int n_active);
 int bmpc_ik_solve_batch_device(const bmpc_ik_batch_t *d, void *hip_stream);
+/* Measurement aid (additive): with profiling on, the DDP loop brackets each of its kernels with events; after a batch solve
+ * bmpc_ik_last_profile returns the summed milliseconds of ik_state / ik_calcdiff / ik_backward / ik_forward and of the rest
+ * of the loop (bench.py's per-kernel split; rocprofv3 --kernel-trace gives the same numbers, profiles/). */
+int bmpc_ik_set_profile(int on);            /* returns the old setting */
+void bmpc_ik_last_profile(double *ms5);
 /* [com, vcom, hg.angular] of x = [q, v]: what KinoDynMP::optimize feeds the centroidal solve (kino_dyn.cpp:42,86-97) */
 int bmpc_ik_centroidal_state_device(const bmpc_model_t *model, const double *x, double *out9, int B, void *hip_stream);
 

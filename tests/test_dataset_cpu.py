@@ -38,7 +38,8 @@ def test_save_layout(tmp_path):
     db = dataset.Database(limit=10)
     rng = np.random.default_rng(1)
     db.append(rng.normal(size=(4, 43)), rng.normal(size=(4, 12)), vc_goals=rng.normal(size=(4, 5)), cc_goals=rng.normal(size=(4, 12)))
-    path = db.save(str(tmp_path), 3, config={"gaits": ["trot"]})
+    cfg = {"gaits": ["trot"], "n_iteration": np.int64(20), "sigma": np.array([0.1, 0.2]), "nested": {"episode_length": 3000, "v": (0.0, 0.3)}}
+    path = db.save(str(tmp_path), 3, config=cfg)
     assert path.endswith("database_3.npz") or path.endswith("database_3.hdf5")
     if path.endswith(".npz"):
         z = np.load(path)
@@ -46,6 +47,15 @@ def test_save_layout(tmp_path):
         assert z["states"].shape == (4, 43) and z["actions"].shape == (4, 12) and z["vc_goals"].shape == (4, 5)
         assert np.array_equal(z["states"], db.states[:4])
     assert (tmp_path / "config.json").exists()
+    # config.pkl: a stdlib pickle of a plain dict, as data_collection.py:116-122 writes it (written once, kept on later saves)
+    import pickle
+    with open(tmp_path / "config.pkl", "rb") as f:
+        got = pickle.load(f)
+    assert got == {"gaits": ["trot"], "n_iteration": 20, "sigma": [0.1, 0.2], "nested": {"episode_length": 3000, "v": [0.0, 0.3]}}
+    assert type(got["n_iteration"]) is int and type(got["sigma"]) is list
+    db.save(str(tmp_path), 4, config={"other": 1})
+    with open(tmp_path / "config.pkl", "rb") as f:
+        assert pickle.load(f) == got
 
 
 def test_vc_goal_rows():
