@@ -160,7 +160,13 @@ def kinodyn_latency(reps=(60, 30), warm=5):
     model = urdf_model.RobotModel.from_json(open(os.path.join(ROOT, "bunmpc_amd", "robots", "solo12.json")).read())
     q0 = problems.SOLO12_Q0.copy()
     gg = SoloMpcGaitGen(model, model, np.concatenate([q0, np.zeros(18)]), 0.05, q0)
-    gg.update_gait_params(problems.TROT, 0.0)
+    import types
+    g, ik = problems.TROT, problems.TROT_IK          # motions/cyclic/solo12_trot.py:12-41 as a BiconvexMotionParams-shaped object
+    gg.update_gait_params(types.SimpleNamespace(
+        gait_period=g.gait_period, stance_percent=list(g.stance_percent), gait_dt=g.gait_dt, phase_offset=list(g.phase_offset),
+        step_ht=g.step_ht, nom_ht=g.nom_ht, gait_horizon=g.gait_horizon, W_X=g.W_X, W_X_ter=g.W_X_ter, W_F=g.W_F, rho=g.rho,
+        ori_correction=list(g.ori_correction), swing_wt=list(ik["swing_wt"]), cent_wt=list(ik["cent_wt"]), reg_wt=list(ik["reg_wt"]),
+        state_wt=ik["state_wt"], ctrl_wt=list(ik["ctrl_wt"])), 0.0)
     gg.kd.compute_solve_times()
     out = {"budget_ms": 50.0}
     import contextlib

@@ -122,6 +122,14 @@ __device__ __forceinline__ float fminR(float a, float b) { return __builtin_fmin
 
 constexpr double kGravity = 9.81;  // centroidal.cpp:63
 
+// Control state of the FISTA / ADMM loops (which problems of the wave still iterate, which are retrying a step, which have
+// finished) is carried as 64-bit LANE MASKS in scalar registers: every decision comes out of a v_cmp as such a mask anyway,
+// combining them is scalar-unit work, and `lanes(m)` turns a mask back into a per-lane predicate (selects and branches take
+// the mask as it is).  As per-lane bools across loop iterations the compiler kept them as 0 / 1 in vector registers: a
+// dozen vector instructions per iteration of pure bookkeeping in an issue-bound kernel.
+typedef unsigned long long mask_t;
+__device__ __forceinline__ bool lanes(mask_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
 // ------------------------------------------------------------------------------
 // Per-iteration algebra (what differs from the reference's formulation, all of it exact
 // algebra on the same quadratic):
@@ -153,6 +161,7 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
     const bool l0 = pvalid && t == 0;      // also owns the x_init rows 9H..9H+8
     const long nx = 9L * (H + 1), nf = (long)NF * H;
     const long pb = pvalid ? prob : 0;
+    const mask_t rvalid_m = __ballot(rvalid), kvalid_m = __ballot(kvalid);
 
     const R m = (R)a.c.m, rho = (R)a.c.rho, mu = (R)a.c.mu, beta = (R)a.c.beta;
     const double tol = a.c.tol, exit_tol = a.c.exit_tol;   // exit tests are evaluated in fp64 whatever R is
@@ -201,12 +210,12 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
         }
         if (l0) { UNROLL for (int l = 0; l < 9; ++l) PIg[l] = (R)PIout[l]; }
     }
-    bool alive = pvalid;
+    mask_t alive = __ballot(pvalid);
     int n_admm = 0, it_f = 0, it_x = 0, bt_f = 0, bt_x = 0, status = 0;
     double last_viol = 0.0;
 
     for (int it = 0; it < a.c.num_iters; ++it) {
-        if (!__any(alive)) break;
+        if (alive == 0) break;
         // contact data of this knot: flags c_n, positions r_n  (centroidal.cpp:39-49); re-read in
         // each phase (L2-resident) rather than held in registers across the FISTA loops
         const double *cg = a.cnt_plan + (pb * H + t) * E * 4;
@@ -234,12 +243,14 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
                 an[n] = c[n] * (dt / m);
                 UNROLL for (int k = 0; k < 3; ++k) sp[n][k] = c[n] * (X[k] - r[n][k]) * dt;
             }
-            R wf[NF], wf2[NF], qf[HASQF ? NF : 1];
+            // The gradient is carried as HALF of itself, gh = Q y + q/2 + rho A^T(A y + bPk), and the step as y - (2/L) gh:
+            // scaling by two is exact in binary floating point, so every iterate has the bits of the reference's
+            // y - g/L, and the doubled copies of the weights (2 Q, 2 rho) need no registers.
+            R wf[NF], qf[HASQF ? NF : 1];
             UNROLL for (int j = 0; j < NF; ++j) {
                 wf[j] = RAW ? ldz<R>(a.Qf, pb * nf + (long)NF * t + j, rvalid)
                             : ldz<R>(a.W_F, pb * a.sW_F + (long)NF * t + j, rvalid);
-                wf2[j] = R(2) * wf[j];
-                if (HASQF) qf[j] = ldz<R>(a.qf, pb * nf + (long)NF * t + j, rvalid);
+                if (HASQF) qf[j] = R(0.5) * ldz<R>(a.qf, pb * nf + (long)NF * t + j, rvalid);
             }
             // u = A v + bPk on rows 9t+3..8
             auto applyA = [&](const R (&v)[NF], R (&u)[6]) {
@@ -263,39 +274,38 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
             UNROLL for (int k = 0; k < 6; ++k) ra[k] = ry[k];
             const R mu2 = mu * mu, imu = R(1) / (mu * mu + R(1));
             const double tol2 = tol * tol;
-            R invL = R(1) / L_f;
-            bool act = alive;
+            R invL = R(2) * (R(1) / L_f);      // 2 / L, see above
+            mask_t act = alive;
             // one FISTA iteration: reads x from xo/ro, leaves x_{k+1} in xn/rn, advances y/ry
             auto iterate = [&](const R (&xo)[NF], const R (&ro)[6], R (&xn)[NF], R (&rn)[6], int i) {
                 const R cm = cmtab[i];
-                // g = 2 Q y + q + 2 rho A^T (A y + bPk)          (problem.cpp:36-38,54-56)
-                R gs[NF];
-                UNROLL for (int n = 0; n < E; ++n) {
-                    const R zx = an[n] * ry[0] - sp[n][2] * ry[4] + sp[n][1] * ry[5];
-                    const R zy = an[n] * ry[1] + sp[n][2] * ry[3] - sp[n][0] * ry[5];
-                    const R zz = an[n] * ry[2] - sp[n][1] * ry[3] + sp[n][0] * ry[4];
-                    gs[3 * n] = fmaR(wf2[3 * n], y[3 * n], rho2 * zx);
-                    gs[3 * n + 1] = fmaR(wf2[3 * n + 1], y[3 * n + 1], rho2 * zy);
-                    gs[3 * n + 2] = fmaR(wf2[3 * n + 2], y[3 * n + 2], rho2 * zz);
-                    if (HASQF) { gs[3 * n] += qf[3 * n]; gs[3 * n + 1] += qf[3 * n + 1]; gs[3 * n + 2] += qf[3 * n + 2]; }
-                }
-                bool done;
-                bool pend = act;
+                mask_t done;
+                mask_t pend = act;
                 for (;;) {  // backtracking (fista.cpp:8-26); segments that accepted recompute the same values
-                    // "SoC" projection exactly as fista.cpp:52-70 writes it
-                    bool anycone = false;
+                    // g/2 = Q y + q/2 + rho A^T (A y + bPk)          (problem.cpp:36-38,54-56), the step y - (2/L) g/2 and the
+                    // "SoC" projection exactly as fista.cpp:52-70 writes it (zeroing by a 0 / 1 factor: one select per foot)
+                    unsigned long long anycone = 0;     // lanes with a force on the cone branch, as a scalar mask
                     R fr[NF];
-                    UNROLL for (int j = 0; j < NF; ++j) fr[j] = fmaR(-gs[j], invL, y[j]);
                     UNROLL for (int n = 0; n < E; ++n) {
+                        const R zx = an[n] * ry[0] - sp[n][2] * ry[4] + sp[n][1] * ry[5];
+                        const R zy = an[n] * ry[1] + sp[n][2] * ry[3] - sp[n][0] * ry[5];
+                        const R zz = an[n] * ry[2] - sp[n][1] * ry[3] + sp[n][0] * ry[4];
+                        R gx = fmaR(wf[3 * n], y[3 * n], rho * zx), gy = fmaR(wf[3 * n + 1], y[3 * n + 1], rho * zy),
+                          gz = fmaR(wf[3 * n + 2], y[3 * n + 2], rho * zz);
+                        if (HASQF) { gx += qf[3 * n]; gy += qf[3 * n + 1]; gz += qf[3 * n + 2]; }
+                        fr[3 * n] = fmaR(-gx, invL, y[3 * n]);
+                        fr[3 * n + 1] = fmaR(-gy, invL, y[3 * n + 1]);
+                        fr[3 * n + 2] = fmaR(-gz, invL, y[3 * n + 2]);
                         const R s = fmaR(fr[3 * n], fr[3 * n], fr[3 * n + 1] * fr[3 * n + 1]);
                         const R fz = fr[3 * n + 2];
                         const bool zero = (s * mu < -fz) || (fz < 0);
-                        anycone = anycone || (!zero && (s > mu * fz));
-                        xn[3 * n] = zero ? R(0) : fr[3 * n];
-                        xn[3 * n + 1] = zero ? R(0) : fr[3 * n + 1];
-                        xn[3 * n + 2] = zero ? R(0) : fz;
+                        anycone |= __ballot(!zero && (s > mu * fz));
+                        const R keep = zero ? R(0) : R(1);
+                        xn[3 * n] = keep * fr[3 * n];
+                        xn[3 * n + 1] = keep * fr[3 * n + 1];
+                        xn[3 * n + 2] = keep * fz;
                     }
-                    if (__any(anycone)) {   // cone branch (fista.cpp:64-68); skipped while no lane needs it
+                    if (anycone != 0) {   // cone branch (fista.cpp:64-68); skipped while no lane needs it
                         UNROLL for (int n = 0; n < E; ++n) {
                             const R s = fmaR(fr[3 * n], fr[3 * n], fr[3 * n + 1] * fr[3 * n + 1]);
                             const R fz = fr[3 * n + 2];
@@ -308,45 +318,62 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
                         }
                     }
                     applyA(xn, rn);
-                    R g2 = 0, cv = 0, e2 = 0;
+                    R g2 = 0, cv = 0, e2 = 0, dv[NF];
                     UNROLL for (int j = 0; j < NF; ++j) {
                         const R d = xn[j] - y[j];
+                        dv[j] = d;
                         g2 = fmaR(d, d, g2);
                         cv = fmaR(wf[j] * d, d, cv);
                     }
-                    UNROLL for (int k = 0; k < 6; ++k) { const R e = rn[k] - ry[k]; e2 = fmaR(e, e, e2); }
+                    if (sizeof(R) == sizeof(double)) {
+                        UNROLL for (int k = 0; k < 6; ++k) { const R e = rn[k] - ry[k]; e2 = fmaR(e, e, e2); }
+                    } else {
+                        // fp32: A d = (A y+ + bPk) - (A y + bPk) by subtraction carries the rounding of the two images (1e-7 of
+                        // |A y|, whatever |d| is); near convergence rho |noise|^2 then exceeds (L/2)|d|^2 and the test retries
+                        // for ever (L_f x 1.5 until it overflows: seen on ~1.5 % of the trot problems).  A applied to d itself
+                        // has the rounding of |A d|.
+                        R s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
+                        UNROLL for (int n = 0; n < E; ++n) {
+                            const R vx = dv[3 * n], vy = dv[3 * n + 1], vz = dv[3 * n + 2];
+                            s0 += an[n] * vx; s1 += an[n] * vy; s2 += an[n] * vz;
+                            s3 += sp[n][2] * vy - sp[n][1] * vz;
+                            s4 += sp[n][0] * vz - sp[n][2] * vx;
+                            s5 += sp[n][1] * vx - sp[n][0] * vy;
+                        }
+                        e2 = s0 * s0 + s1 * s1 + s2 * s2 + s3 * s3 + s4 * s4 + s5 * s5;
+                    }
                     cv = fmaR(rho, e2, cv);
                     const double g2s = seg_sum<LPP>((double)g2), cvs = seg_sum<LPP>((double)cv);
                     // fista.cpp:14-17: G = sqrt(g2); retry if cv > (L/2) G*G; done if G < tol.  G*G and g2
                     // differ by a few ulp, so outside a 1e-14 relative band the sqrt cannot change either
                     // decision; inside it the reference expression is evaluated as written.
                     const double Lh = (double)L_f * 0.5, rhs = Lh * g2s;
-                    bool bt = cvs > rhs;
-                    done = g2s < tol2;
-                    const bool edge = (fabs(cvs - rhs) <= 1e-14 * rhs) || (fabs(g2s - tol2) <= 1e-14 * tol2);
-                    if (__any(edge)) {
+                    mask_t bt = __ballot(cvs > rhs);
+                    done = __ballot(g2s < tol2);
+                    const mask_t edge = __ballot((fabs(cvs - rhs) <= 1e-14 * rhs) || (fabs(g2s - tol2) <= 1e-14 * tol2));
+                    if (edge != 0) {
                         const double Gn = sqrt(g2s);
-                        bt = cvs > Lh * (Gn * Gn);
-                        done = Gn < tol;
+                        bt = __ballot(cvs > Lh * (Gn * Gn));
+                        done = __ballot(Gn < tol);
                     }
-                    bt = bt && pend;
+                    bt &= pend;
                     pend = bt;
-                    if (!__any(bt)) break;
-                    if (bt) { L_f *= beta; ++bt_f; }
-                    invL = R(1) / L_f;
+                    if (bt == 0) break;
+                    if (lanes(bt)) { L_f *= beta; ++bt_f; }
+                    invL = R(2) * (R(1) / L_f);
                 }
-                const bool last = act && (done || i == maxit - 1);
-                if (last && rvalid) { UNROLL for (int j = 0; j < NF; ++j) Fg[j] = xn[j]; }   // x_k of a finishing problem is latched
+                const mask_t last = act & (i == maxit - 1 ? ~mask_t(0) : done) & rvalid_m;
+                if (lanes(last)) { UNROLL for (int j = 0; j < NF; ++j) Fg[j] = xn[j]; }   // x_k of a finishing problem is latched
                 // momentum (fista.cpp:33-47); A-images follow by linearity
                 UNROLL for (int j = 0; j < NF; ++j) y[j] = fmaR(cm, xn[j] - xo[j], xn[j]);
                 UNROLL for (int k = 0; k < 6; ++k) ry[k] = fmaR(cm, rn[k] - ro[k], rn[k]);
-                it_f += act ? 1 : 0;
-                act = act && !done;
+                it_f += lanes(act) ? 1 : 0;
+                act &= ~done;
             };
             for (int i = 0; i < maxit; i += 2) {
-                if (!__any(act)) break;
+                if (act == 0) break;
                 iterate(xa, ra, xb, rb, i);
-                if (i + 1 >= maxit || !__any(act)) break;
+                if (i + 1 >= maxit || act == 0) break;
                 iterate(xb, rb, xa, ra, i + 1);
             }
         }
@@ -382,7 +409,7 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
             if (RAW) {
                 UNROLL for (int l = 0; l < 9; ++l) {
                     qd[l] = ldz<R>(a.Qx, pb * nx + 9L * t + l, kvalid);
-                    q[l] = ldz<R>(a.qx, pb * nx + 9L * t + l, kvalid);
+                    q[l] = R(0.5) * ldz<R>(a.qx, pb * nx + 9L * t + l, kvalid);     // q/2
                 }
                 UNROLL for (int l = 0; l < NB; ++l) {
                     lb[l] = kvalid ? (R)a.lbx[pb * nx + 9L * t + l] : R(-INFINITY);
@@ -396,7 +423,7 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
                     const R xr = (R)(rvalid ? a.X_nom[pb * 9L * H + 9L * t + l]
                                                  : (kvalid ? a.X_ter[pb * 9 + l] : 0.0));
                     qd[l] = w;
-                    q[l] = R(-2) * (xr * w);
+                    q[l] = -(xr * w);              // q/2 (create_cost_X: q = -2 W x_ref)
                 }
                 // create_bound_constraints (biconvex.cpp:27-55): CoM box around the feet
                 R csum = 0;
@@ -411,13 +438,12 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
                     ub[k] = bounded ? mn + bhi : R(INFINITY);
                 }
             }
-            // x_init rows folded into lane 0's diagonal cost:  rho |X_0 + (P_H - x_init)|^2
-            R qd2[9];
+            // x_init rows folded into lane 0's diagonal cost:  rho |X_0 + (P_H - x_init)|^2   (q holds q/2: half-gradient form,
+            // see the force step)
             UNROLL for (int l = 0; l < 9; ++l) {
                 const R bpi = l0 ? (PIg[l] - (R)a.x_init[pb * 9 + l]) : R(0);
                 qd[l] += l0 ? rho : R(0);
-                q[l] += rho2 * bpi;
-                qd2[l] = R(2) * qd[l];
+                q[l] = fmaR(rho, bpi, q[l]);
             }
             UNROLL for (int l = 0; l < NB; ++l) {   // quieted once, so the clamp is a bare min/max pair
                 lb[l] = __builtin_canonicalize(lb[l]);
@@ -442,28 +468,28 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
             applyA(y, ry);
             UNROLL for (int l = 0; l < 9; ++l) ra[l] = ry[l];
             const double tol2 = tol * tol;
-            R invL = R(1) / L_x;
-            bool act = alive;
+            R invL = R(2) * (R(1) / L_x);
+            mask_t act = alive;
             auto iterate = [&](const R (&xo)[9], const R (&ro)[9], R (&xn)[9], R (&rn)[9], int i) {
                 const R cm = cmtab[i];
-                R gs[9];
-                {   // gradient 2 Q y + q + 2 rho A_f^T (A_f y + bPk)
-                    R z[9], wp[9];
-                    UNROLL for (int l = 0; l < 9; ++l) wp[l] = from_prev(ry[l]);  // row-block t-1 (0 for t == 0)
-                    UNROLL for (int l = 0; l < 9; ++l) z[l] = ry[l] - wp[l];
-                    UNROLL for (int k = 0; k < 3; ++k) z[3 + k] = fmaR(dtp, wp[k], z[3 + k]);
-                    z[0] += SZ * ry[7] - SY * ry[8];
-                    z[1] += SX * ry[8] - SZ * ry[6];
-                    z[2] += SY * ry[6] - SX * ry[7];
-                    UNROLL for (int l = 0; l < 9; ++l) gs[l] = fmaR(qd2[l], y[l], fmaR(rho2, z[l], q[l]));
-                }
-                bool done;
-                bool pend = act;
+                mask_t done;
+                mask_t pend = act;
                 for (;;) {
-                    UNROLL for (int l = 0; l < 9; ++l) {
-                        R v = fmaR(-gs[l], invL, y[l]);
-                        if (l < NB) v = fmaxR(fminR(v, ub[l]), lb[l]);   // fista.cpp:10
-                        xn[l] = v;
+                    {   // half gradient Q y + q/2 + rho A_f^T (A_f y + bPk), step, box projection (fista.cpp:10); inside the retry
+                        // loop like the force step's
+                        R z[9], wp[9];
+                        UNROLL for (int l = 0; l < 9; ++l) wp[l] = from_prev(ry[l]);  // row-block t-1 (0 for t == 0)
+                        UNROLL for (int l = 0; l < 9; ++l) z[l] = ry[l] - wp[l];
+                        UNROLL for (int k = 0; k < 3; ++k) z[3 + k] = fmaR(dtp, wp[k], z[3 + k]);
+                        z[0] += SZ * ry[7] - SY * ry[8];
+                        z[1] += SX * ry[8] - SZ * ry[6];
+                        z[2] += SY * ry[6] - SX * ry[7];
+                        UNROLL for (int l = 0; l < 9; ++l) {
+                            const R g = fmaR(qd[l], y[l], fmaR(rho, z[l], q[l]));
+                            R v = fmaR(-g, invL, y[l]);
+                            if (l < NB) v = fmaxR(fminR(v, ub[l]), lb[l]);
+                            xn[l] = v;
+                        }
                     }
                     applyA(xn, rn);
                     R g2 = 0, cv = 0, e2 = 0;
@@ -477,33 +503,33 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
                     cv = fmaR(rho, e2, cv);
                     const double g2s = seg_sum<LPP>((double)g2), cvs = seg_sum<LPP>((double)cv);
                     const double Lh = (double)L_x * 0.5, rhs = Lh * g2s;   // see the force loop for the sqrt-free form
-                    bool bt = cvs > rhs;
-                    done = g2s < tol2;
-                    const bool edge = (fabs(cvs - rhs) <= 1e-14 * rhs) || (fabs(g2s - tol2) <= 1e-14 * tol2);
-                    if (__any(edge)) {
+                    mask_t bt = __ballot(cvs > rhs);
+                    done = __ballot(g2s < tol2);
+                    const mask_t edge = __ballot((fabs(cvs - rhs) <= 1e-14 * rhs) || (fabs(g2s - tol2) <= 1e-14 * tol2));
+                    if (edge != 0) {
                         const double Gn = sqrt(g2s);
-                        bt = cvs > Lh * (Gn * Gn);
-                        done = Gn < tol;
+                        bt = __ballot(cvs > Lh * (Gn * Gn));
+                        done = __ballot(Gn < tol);
                     }
-                    bt = bt && pend;
+                    bt &= pend;
                     pend = bt;
-                    if (!__any(bt)) break;
-                    if (bt) { L_x *= beta; ++bt_x; }
-                    invL = R(1) / L_x;
+                    if (bt == 0) break;
+                    if (lanes(bt)) { L_x *= beta; ++bt_x; }
+                    invL = R(2) * (R(1) / L_x);
                 }
-                const bool last = act && (done || i == maxit - 1);
-                if (last && kvalid) { UNROLL for (int l = 0; l < 9; ++l) Xg[l] = xn[l]; }
+                const mask_t last = act & (i == maxit - 1 ? ~mask_t(0) : done) & kvalid_m;
+                if (lanes(last)) { UNROLL for (int l = 0; l < 9; ++l) Xg[l] = xn[l]; }
                 UNROLL for (int l = 0; l < 9; ++l) {
                     y[l] = fmaR(cm, xn[l] - xo[l], xn[l]);
                     ry[l] = fmaR(cm, rn[l] - ro[l], rn[l]);
                 }
-                it_x += act ? 1 : 0;
-                act = act && !done;
+                it_x += lanes(act) ? 1 : 0;
+                act &= ~done;
             };
             for (int i = 0; i < maxit; i += 2) {
-                if (!__any(act)) break;
+                if (act == 0) break;
                 iterate(xa, ra, xb, rb, i);
-                if (i + 1 >= maxit || !__any(act)) break;
+                if (i + 1 >= maxit || act == 0) break;
                 iterate(xb, rb, xa, ra, i + 1);
             }
             R fin[9];
@@ -519,23 +545,24 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
                 w[6] += SY * fin[2] - SZ * fin[1];
                 w[7] += SZ * fin[0] - SX * fin[2];
                 w[8] += SX * fin[1] - SY * fin[0];
+                const bool al = lanes(alive);
                 UNROLL for (int l = 0; l < 9; ++l) {
                     const R d = rvalid ? (w[l] - bf[l]) : R(0);
                     const R di = l0 ? (fin[l] - (R)a.x_init[pb * 9 + l]) : R(0);
-                    if (alive && rvalid) Pg[l] += d;
-                    if (alive && l0) PIg[l] += di;
+                    if (al && rvalid) Pg[l] += d;
+                    if (al && l0) PIg[l] += di;
                     v2 += (double)d * (double)d + (double)di * (double)di;
                 }
             }
             v2 = seg_sum<LPP>(v2);
             const double nrm = sqrt(v2);
-            if (alive) {
+            if (lanes(alive)) {
                 last_viol = nrm;
                 ++n_admm;
                 if (a.hist && l0) a.hist[pb * a.c.num_iters + it] = nrm;
-                if (isnan(nrm)) { status = 2; alive = false; }       // biconvex.cpp:106-109
-                else if (nrm < exit_tol) alive = false;               // biconvex.cpp:111-114
+                if (isnan(nrm)) status = 2;                                   // biconvex.cpp:106-109
             }
+            alive &= ~__ballot(isnan(nrm) || nrm < exit_tol);                 // biconvex.cpp:106-109, 111-114
         }
     }
 

@@ -10,7 +10,7 @@ import pytest
 
 from bunmpc_amd import batch as bb
 from bunmpc_amd import problems
-from tests.util import rel_l2
+from tests.util import cpu_spread, rel_l2, within_envelope
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -43,38 +43,38 @@ def test_chaotic_envelope(oracle, config, B):
     """The reference's "SoC" projection (fista.cpp:52-70) uses the SQUARED tangential norm; on
     its cone branch (s > mu z) it is expansive once |f_xy| > ~0.5 N, the force FISTA then never
     converges (G stays ~1e-2 for all 150 iterations) and rounding differences grow ~x1.12 per
-    iteration.  Bound / pace problems enter that regime after a few ADMM iterations: the two CPU
-    restatements (same formulas, different summation order) then differ by up to ~8e-4 rel-L2
-    (tests/test_oracle_cpu.py::test_restatements_spread).  The GPU is held to that envelope, the
-    same ADMM count / status, and the solution invariants (test_invariants_*)."""
+    iteration.  Bound / pace problems enter that regime after a few ADMM iterations: the CPU
+    restatements (same formulas, different summation order) then differ by 1e-4 ... 4e-3 rel-L2.
+    The GPU is held, problem by problem, to 10 x the spread the three CPU restatements show on that
+    very problem (tests/util.py: measured ratio <= 2.7), to 1e-5 where they agree, to the same ADMM
+    count / status, and to the solution invariants (test_full_size_*)."""
     b = problems.make_batch(config, B)
-    ref = oracle.solve_batch(b, num_iters=10)
+    ref, spread = cpu_spread(b, 10, oracle)
     got = bb.solve_host(b, num_iters=10)
     assert np.array_equal(got["stats"][:, [0, 5]], ref["stats"][:, [0, 5]])
-    for k in ("X", "F", "P"):
-        err = rel_l2(got[k], ref[k])
-        assert np.all(err < 5e-3), (k, err)
-    print(config, "rel err X", rel_l2(got["X"], ref["X"]))
+    err, bound = within_envelope(got, ref, spread)
+    assert np.all(err <= bound), (err, bound)
+    print(config, "GPU-C rel err", err, "CPU spread", spread)
 
 
 def test_hundred_admm_iterations(oracle):
     """The reference's own call is kd.optimize(q, v, 100, 1) (abstract_cyclic_gen.py:663).  Over
-    ~60-100 ADMM iterations the algorithm amplifies rounding-order differences: the two CPU
-    restatements (C vs numpy, both following the reference) differ by up to ~5e-4 rel-L2 here and
-    can exit one ADMM iteration apart when ||dyn|| crosses exit_tol = 1e-3 within rounding (see
-    tests/test_oracle_cpu.py::test_restatements_spread_at_100_iterations).  The GPU is held to the
-    same envelope, plus the exit condition itself."""
+    ~60-100 ADMM iterations the algorithm amplifies rounding-order differences: the CPU
+    restatements differ by up to ~5e-4 rel-L2 here and can exit one ADMM iteration apart when
+    ||dyn|| crosses exit_tol = 1e-3 within rounding (tests/test_oracle_cpu.py::
+    test_restatements_spread_at_100_iterations).  The GPU is held to 10 x the CPU spread measured on
+    each problem (1e-5 where the CPU restatements agree), plus the exit condition itself."""
     b = problems.make_batch("solo12_trot", 5)
-    ref = oracle.solve_batch(b, num_iters=100)
+    ref, spread = cpu_spread(b, 100, oracle)
     got = bb.solve_host(b, num_iters=100)
     assert np.all(np.abs(got["stats"][:, 0] - ref["stats"][:, 0]) <= 1)
-    for k in ("X", "F", "P"):
-        err = rel_l2(got[k], ref[k])
-        assert np.all(err < 5e-3), (k, err)
+    err, bound = within_envelope(got, ref, spread)
+    assert np.all(err <= bound), (err, bound)
     done = got["stats"][:, 0] < 100
     assert np.all(got["dyn_viol"][done] < 1e-3)
     same = np.all(got["stats"] == ref["stats"], axis=1)
-    print("100 iters: rel err X", rel_l2(got["X"], ref["X"]), "same discrete path:", same)
+    assert np.all(same[spread < 1e-9])             # where the CPU restatements agree the discrete path is identical
+    print("100 iters: GPU-C rel err", err, "CPU spread", spread, "same discrete path:", same)
 
 
 GOLDEN = sorted(__import__("glob").glob(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "*.npz")))
@@ -174,15 +174,14 @@ def test_horizons_and_ragged_batches(oracle, H):
     B = 7
     b = problems.make_batch("solo12_trot", B, H=H)
     iters = 2 if H < 40 else 1       # long horizons enter the chaotic regime (test_chaotic_envelope) sooner
-    ref = oracle.solve_batch(b, num_iters=iters)
+    ref, spread = cpu_spread(b, iters, oracle, with_numpy=H >= 40)
     got = bb.solve_host(b, num_iters=iters)
     assert np.array_equal(got["stats"], ref["stats"])
-    for k in "XFP":
-        err = rel_l2(got[k], ref[k])
-        if H < 40:
-            assert np.all(err < TOL), (k, err)
-        else:   # 3 s horizons amplify rounding already inside the first ADMM iteration
-            assert np.median(err) < 1e-8 and np.all(err < 5e-3), (k, err)
+    err, bound = within_envelope(got, ref, spread)
+    if H < 40:
+        assert np.all(err < TOL) and np.all(rel_l2(got["P"], ref["P"]) < TOL), err
+    else:   # 3 s horizons amplify rounding already inside the first ADMM iteration: 10 x the CPU spread of each problem
+        assert np.median(err) < 1e-8 and np.all(err <= bound), (err, bound)
 
 
 def test_unsupported_shapes_are_refused():
@@ -250,12 +249,12 @@ def test_full_size_invariants_and_sampled_parity(oracle):
     again = dev.results()
     for k in "XFP":
         assert np.array_equal(again[k], got[k])
-    ref = oracle.solve_batch(b.take(sub), num_iters=10)
-    err = np.maximum(rel_l2(got["X"][sub], ref["X"]), rel_l2(got["F"][sub], ref["F"]))
-    print("sampled parity over %d problems: median %.2e, max %.2e, above 1e-5: %d"
-          % (len(sub), np.median(err), err.max(), (err > TOL).sum()))
+    ref, spread = cpu_spread(b.take(sub), 10, oracle)
+    err, bound = within_envelope({k: got[k][sub] for k in "XF"}, ref, spread)
+    print("sampled parity over %d problems: median %.2e, max %.2e, above 1e-5: %d; CPU spread max %.2e"
+          % (len(sub), np.median(err), err.max(), (err > TOL).sum(), spread.max()))
     assert np.median(err) < 1e-12
-    assert np.all(err < 5e-3) and (err > TOL).mean() <= 0.1     # chaotic-regime problems, see test_chaotic_envelope
+    assert np.all(err <= bound)         # 1e-5 wherever the CPU restatements agree (all 64 here: measured 7e-15)
 
 
 @pytest.mark.parametrize("config,B,H", [("go2_bound", 256, 40), ("solo12_trot", 256, None)])

@@ -1,0 +1,190 @@
+"""Parity checks the round-1 review asked for (VERDICT.md "Next round" item 1), all through the C-ABI on the GPU:
+ (a) the fp32 kernel (BASELINE config 3) against the CPU ORACLE, not against its fp64 sibling;
+ (c) whole-body DDP problems that run into crocoddyl's maxiter = 100 (synthetic Go2, H = 60 / H_ik = 30): the GPU and the
+     compiled CPU twin must take the same 100 iterations -- same accepted step lengths, same regularisation sequence, same cost;
+ (d) full-size property checks for the Go2 shapes (H = 40, B = 4096, fp64 and fp32; H = 60 / H_ik = 30, B = 1024 with the IK).
+The measured-spread envelope of item (b) lives in tests/util.py and is used by tests/test_biconvex_gpu.py.
+PARITY UNPINNED throughout: the reference holds no vectors for this path and cannot be built here."""
+import dataclasses
+import os
+
+import numpy as np
+import pytest
+
+from bunmpc_amd import batch as bb
+from bunmpc_amd import problems, urdf_model
+from tests.util import cpu_spread, rel_l2, within_envelope
+
+pytestmark = pytest.mark.gpu
+ROBOTS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bunmpc_amd", "robots")
+
+# fp32 tolerance against the fp64 CPU oracle.  The iterates are fp32 (unit round-off 6e-8) through ~2 500 FISTA iterations per
+# solve; every decision is taken in fp64.  Measured on the MI355X (tools/fp32_diag.py, 1024 problems per shape): median 2e-6;
+# synthetic Go2 bound H = 40: every problem below 4e-5; Solo12 trot: 98.7 % of the problems below 1e-5 -- inside north_star's
+# fp64 tolerance -- and 1.3 % between 1e-4 and 5e-3.  Those stop their force FISTA a few iterations away from the oracle:
+# its exit test ||y+ - y|| < 1e-5 sits at the resolution of an fp32 force iterate (240 components of ~10 N x 6e-8), a property
+# of running the reference's absolute tolerance in fp32, not of the kernel (the ADMM count stays the oracle's).  Held to:
+# median <= 5e-6, 95 % <= 1e-5, every calm problem <= 1e-2; problems in the chaotic regime of the reference algorithm
+# (tests/util.py), where a 1e-7 perturbation is amplified like any other, must keep the oracle's ADMM count, stay finite and
+# satisfy the invariants.  (The first version of this test caught a real defect: the fp32 backtracking test took A d as the
+# difference of two rounded images and retried for ever on ~1.5 % of the trot problems -- rel. error 0.5; biconvex_admm.hip.)
+FP32_MEDIAN, FP32_P95, FP32_MAX = 5e-6, 1e-5, 1e-2
+
+
+@pytest.mark.parametrize("config,B,H", [("go2_bound", 256, 40), ("solo12_trot", 256, None), ("solo12_mixed", 96, None)])
+def test_fp32_kernel_against_the_cpu_oracle(oracle, config, B, H):
+    b = problems.make_batch(config, B, H=H) if H else problems.make_batch(config, B)
+    ref, spread = cpu_spread(b, 10, oracle, with_numpy=False)
+    got = bb.solve_host(b, num_iters=10, precision="f32")
+    assert np.array_equal(got["stats"][:, [0, 5]], ref["stats"][:, [0, 5]])          # the oracle's ADMM count, nothing diverged
+    err = np.maximum(rel_l2(got["X"], ref["X"]), rel_l2(got["F"], ref["F"]))
+    calm = spread <= 1e-9
+    print("%s fp32 vs CPU oracle: calm %d problems median %.2e p95 %.2e max %.2e | chaotic %d problems max %.2e (CPU spread max %.2e)"
+          % (config, calm.sum(), np.median(err[calm]), np.quantile(err[calm], 0.95), err[calm].max(), (~calm).sum(),
+             err[~calm].max() if (~calm).any() else 0.0, spread.max()))
+    assert np.median(err[calm]) <= FP32_MEDIAN and np.quantile(err[calm], 0.95) <= FP32_P95 and np.all(err[calm] <= FP32_MAX)
+    if config != "solo12_mixed":
+        assert calm.mean() > 0.9
+    assert np.all(np.isfinite(got["X"])) and np.all(np.isfinite(got["F"]))
+    F = got["F"].reshape(B, b.H, b.E, 3)
+    assert np.all(F[b.cnt_plan[..., 0] == 0] == 0.0) and np.all(F[..., 2] >= 0)
+    # the fp64 residual check of config 3: the violation the kernel reports, re-derived in fp64 from the returned iterates
+    for i in range(0, B, 16):
+        A, bf = oracle.dense_A_f(b.cnt_plan[i], b.dt[i], b.m, got["F"][i], b.x_init[i])
+        r = np.linalg.norm(A @ got["X"][i] - bf)
+        assert abs(r - got["dyn_viol"][i]) <= 1e-4 * max(r, 1e-3), (i, r, got["dyn_viol"][i])
+
+
+def _go2_wb(B, first=0):
+    go2 = urdf_model.RobotModel.from_json(open(os.path.join(ROBOTS, "go2.json")).read())
+    wb = problems.make_wb_batch(go2, B, first=first, gait=dataclasses.replace(problems.TROT, nom_ht=0.30, gait_horizon=6.0), wb=problems.GO2_WB)
+    return go2, wb
+
+
+def test_ddp_problems_that_hit_maxiter_follow_the_cpu_twin():
+    """Problems 2, 13 and 14 of the bench's Go2 H = 60 batch never reach SolverDDP's stopping threshold (|Q_u|^2 < 1e-9) within
+    its 100 iterations.  Not a regularisation limit cycle: the regularisation stays at its floor (1e-9) and the cost falls
+    monotonically -- the Gauss-Newton DDP converges linearly with partial steps (alpha 1/16 ... 1/2) on these plans and simply
+    runs out of iterations.  GPU and CPU twin must agree on every discrete decision along the way."""
+    from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
+    from oracle import ik_oracle_c as ic
+    go2, wb = _go2_wb(16)
+    kb = KinoDynDeviceBatch(wb, go2, num_iters=10)
+    kb.solve()
+    g = kb.results()
+    r = ic.solve_wb_batch(ic.Model(go2), wb, g["X"], trace=True)
+    long_runs = np.where(r["status"] == 1)[0]
+    assert len(long_runs) >= 3 and {2, 13, 14} <= set(long_runs.tolist())
+    assert np.array_equal(g["ik_iters"], r["iters"]) and np.array_equal(g["ik_status"], r["status"])
+    for i in range(16):
+        n = int(r["iters"][i])
+        tg, tc = g["ik_trace"][i, :n], r["trace"][i, :n]
+        assert np.array_equal(tg[:, 1], tc[:, 1]), i                     # regularisation after every iteration
+        assert np.array_equal(tg[:, 2], tc[:, 2]), i                     # accepted step length of every iteration
+        assert np.all(np.abs(tg[:, 0] - tc[:, 0]) <= 1e-6 * np.abs(tc[:, 0])), i     # cost after every iteration
+        assert abs(g["ik_cost"][i] - r["cost"][i]) <= 1e-9 * abs(r["cost"][i])
+        assert rel_l2(g["xs"][i].reshape(-1), r["xs"][i].reshape(-1)) < 1e-6
+    for i in long_runs:
+        tr = g["ik_trace"][i, :100]
+        assert r["iters"][i] == 100 and g["ik_status"][i] == 1
+        assert np.all(tr[:, 1] <= 1e-8)                                  # regularisation never leaves its floor: no limit cycle
+        assert np.all(np.diff(tr[1:, 0]) <= 0) and np.all(tr[:, 2] > 0)  # every iteration accepts a step and lowers the cost
+        assert tr[-1, 3] > 1e-9                                          # ... but the stopping criterion is not reached
+
+
+def _centroidal_invariants(b, got, oracle, mu):
+    B, H, E = b.B, b.H, b.E
+    assert np.all(got["stats"][:, 5] == 0) and np.all(got["stats"][:, 0] == 10)
+    F = got["F"].reshape(B, H, E, 3)
+    assert np.all(F[b.cnt_plan[..., 0] == 0] == 0.0)                  # swing feet carry no force
+    s = F[..., 0] ** 2 + F[..., 1] ** 2
+    assert np.all(F[..., 2] >= 0) and np.all(s <= mu * F[..., 2] * (1 + 1e-6) + 1e-9)   # image of the reference's "SoC" map
+    X = got["X"].reshape(B, H + 1, 9)
+    assert np.all(np.isfinite(X)) and np.all(np.abs(X[:, 0] - b.x_init) < 5e-2)
+    for i in np.arange(0, B, 512):
+        A, bf = oracle.dense_A_f(b.cnt_plan[i], b.dt[i], b.m, got["F"][i], b.x_init[i])
+        r = np.linalg.norm(A @ got["X"][i] - bf)
+        assert abs(r - got["dyn_viol"][i]) <= 1e-4 * max(r, 1e-3)
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_full_size_go2_bound_h40(oracle, precision):
+    """BASELINE config 3 at its full size (B = 4096, H = 40) through the device-resident path: size-independent properties
+    on every problem, oracle parity on a 64-problem sample.  (Synthetic Go2 runs with mu = 10, not the reference's mu = 1:
+    the reference algorithm NaNs for a 15 kg robot at mu = 1, tests/test_oracle_cpu.py.)"""
+    B = 4096
+    b = problems.make_batch("go2_bound", B, H=40)
+    dev = bb.DeviceBatch(b, num_iters=10, precision=precision)
+    dev.solve()
+    got = dev.results()
+    _centroidal_invariants(b, got, oracle, b.mu)
+    dev.solve()
+    again = dev.results()
+    for k in "XFP":
+        assert np.array_equal(again[k], got[k])                       # deterministic reductions: bit-identical re-solve
+    sub = np.arange(0, B, 64)
+    ref, spread = cpu_spread(b.take(sub), 10, oracle)
+    err, bound = within_envelope({k: got[k][sub] for k in "XF"}, ref, spread)
+    assert np.array_equal(got["stats"][sub][:, [0, 5]], ref["stats"][:, [0, 5]])
+    print("go2_bound H=40 B=4096 %s: sampled parity median %.2e max %.2e; CPU spread max %.2e" % (precision, np.median(err), err.max(), spread.max()))
+    if precision == "f64":
+        assert np.all(err <= bound) and np.median(err) < 1e-12
+    else:
+        calm = spread <= 1e-9
+        assert np.median(err[calm]) <= FP32_MEDIAN and np.all(err[calm] <= FP32_MAX)
+
+
+def test_full_size_go2_h60_kinodyn(oracle):
+    """BASELINE config 5's per-GPU share (synthetic Go2, trot, H = 60 / H_ik = 30, B = 1024): properties of every solution and
+    twin parity on a sample."""
+    from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
+    from oracle import ik_oracle_c as ic
+    B = 1024
+    go2, wb = _go2_wb(B)
+    T, H = wb.ik_T, wb.dyn.H
+    kb = KinoDynDeviceBatch(wb, go2, num_iters=10)
+    kb.solve()
+    g = kb.results()
+    # centroidal part
+    assert np.all(g["stats"][:, 5] == 0) and np.all(np.isfinite(g["X"]))
+    F = g["F"].reshape(B, H, 4, 3)
+    assert np.all(F[wb.dyn.cnt_plan[..., 0] == 0] == 0.0) and np.all(F[..., 2] >= 0)
+    # whole-body part: statuses, stopping criterion, the trajectory is a rollout of its own controls from x0
+    st = g["ik_status"]
+    assert set(np.unique(st).tolist()) <= {0, 1} and np.all(g["ik_iters"][st == 1] == 100) and np.all(g["ik_stop"][st == 0] < 1e-9)
+    assert 0.02 < (st == 1).mean() < 0.12                               # ~6 % run out of iterations (see the maxiter test above)
+    xs, us, dt = g["xs"], g["us"], wb.dyn.dt[:, :T]
+    assert np.array_equal(xs[:, 0], wb.x)
+    v, a = xs[:, :-1, 19:], us
+    assert np.abs(xs[:, 1:, 19:] - (v + a * dt[:, :, None])).max() < 1e-12                                  # v+ = v + a dt
+    assert np.abs(xs[:, 1:, 7:19] - (xs[:, :-1, 7:19] + v[:, :, 6:] * dt[:, :, None] + a[:, :, 6:] * dt[:, :, None] ** 2)).max() < 1e-12
+    assert np.abs(np.linalg.norm(xs[:, :, 3:7], axis=2) - 1.0).max() < 1e-12
+    m = ic.Model(go2)
+    for i in range(0, B, 128):          # base block of the Euler step through the CPU twin's integrate
+        for t in range(0, T, 7):
+            dx = np.concatenate([xs[i, t, 19:] * dt[i, t] + us[i, t] * dt[i, t] ** 2, us[i, t] * dt[i, t]])
+            assert np.abs(ic.state_ops(m, xs[i, t], xs[i, t], dx)["xint"] - xs[i, t + 1]).max() < 1e-12
+    # cost reported = cost of the returned trajectory, recomputed by the CPU twin's node model
+    tasks = np.array(wb.ik_tasks)
+    Xk = g["X"].reshape(B, H + 1, 9)[:, :T + 1]
+    tasks[:, :, 21:24], tasks[:, :, 25:28], tasks[:, :, 28:31] = Xk[:, :, 0:3], wb.dyn.m * Xk[:, :, 3:6], Xk[:, :, 6:9]
+    for i in range(0, B, 256):
+        c = sum(ic.node(m, T, t, dt[i], tasks[i], wb.state_w[0], wb.x_reg[i], wb.ctrl_w[0], xs[i, t], us[i, t] if t < T else None)["cost"]
+                for t in range(T + 1))
+        assert abs(c - g["ik_cost"][i]) <= 1e-10 * abs(c)
+    # a second solve is bit-identical
+    kb.solve()
+    g2 = kb.results()
+    assert np.array_equal(g2["xs"], g["xs"]) and np.array_equal(g2["ik_iters"], g["ik_iters"]) and np.array_equal(g2["X"], g["X"])
+    # sampled parity: the CPU twin on the GPU's own centroidal solution
+    sub = np.arange(0, B, 64)
+    r = ic.solve_wb_batch(m, wb.take(sub), g["X"][sub])
+    assert np.array_equal(r["iters"], g["ik_iters"][sub]) and np.array_equal(r["status"], st[sub])
+    assert np.all(np.abs(r["cost"] - g["ik_cost"][sub]) <= 1e-8 * np.abs(r["cost"]))
+    e = rel_l2(g["xs"][sub].reshape(len(sub), -1), r["xs"].reshape(len(sub), -1))
+    print("go2 H=60 B=1024: DDP iterations mean %.1f, not converged %d, sampled xs rel-L2 vs CPU twin max %.2e" % (g["ik_iters"].mean(), (st == 1).sum(), e.max()))
+    assert np.all(e < 1e-6)
+    # centroidal sample against the strict oracle, in the measured envelope
+    ref, spread = cpu_spread(wb.dyn.take(sub[:8]), 10, oracle)
+    err, bound = within_envelope({k: g[k][sub[:8]] for k in "XF"}, ref, spread)
+    assert np.all(err <= bound), (err, bound)

@@ -7,3 +7,36 @@ def rel_l2(a, b):
     if a.ndim == 1:
         return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
     return np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-300)
+
+
+# ---- the envelope the GPU is held to where the reference algorithm itself is chaotic --------------------------
+# Where the force FISTA sits on the expansive branch of the reference's "SoC" projection, rounding-order differences grow
+# ~x1.12 per iteration and ANY two faithful implementations drift apart.  The three CPU restatements (strict C, matrix-free C,
+# numpy twin) measure that drift on the very problems under test; the GPU, one more implementation with its own summation
+# order, must stay within K_SPREAD times the largest pairwise distance among them -- and within north_star's 1e-5 wherever
+# they agree.  K_SPREAD = 10: measured on the MI355X (tools/calibrate_parity.py, gpurun_out log of round 2) the ratio
+# GPU-distance / CPU-spread over all chaotic problems of these tests has median 0.3-1.0 and maximum 2.7.
+TOL_FP64 = 1e-5
+K_SPREAD = 10.0
+
+
+def cpu_spread(b, iters, oracle, with_numpy=True, **kw):
+    """strict C solution of batch b and, per problem, the largest pairwise rel-L2 distance (X and F) among the CPU restatements"""
+    from oracle import oracle_np
+    ref = oracle.solve_batch(b, num_iters=iters, **kw)
+    fast = oracle.solve_batch(b, num_iters=iters, fast=True, **kw)
+    s = np.maximum(rel_l2(fast["X"], ref["X"]), rel_l2(fast["F"], ref["F"]))
+    if with_numpy:
+        X0, F0, P0 = b.warm_start()
+        for i in range(b.B):
+            rn = oracle_np.biconvex_solve(b.cnt_plan[i], b.dt[i], b.m, b.x_init[i], ref["Qx"][i], ref["qx"][i], ref["Qf"][i], ref["lbx"][i],
+                                          ref["ubx"][i], X0[i], F0[i], P0[i], rho=b.rho, num_iters=iters, mu=b.mu,
+                                          **{k: v for k, v in kw.items() if k in ("maxit", "tol", "exit_tol")})
+            s[i] = max(s[i], rel_l2(rn["X"], ref["X"][i]), rel_l2(rn["F"], ref["F"][i]), rel_l2(rn["X"], fast["X"][i]), rel_l2(rn["F"], fast["F"][i]))
+    return ref, s
+
+
+def within_envelope(got, ref, spread):
+    """per problem: max(rel-L2 X, rel-L2 F) of the GPU result against the strict C solution, and the bound it must meet"""
+    e = np.maximum(rel_l2(got["X"], ref["X"]), rel_l2(got["F"], ref["F"]))
+    return e, np.maximum(TOL_FP64, K_SPREAD * spread)
