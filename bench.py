@@ -150,6 +150,23 @@ def p50_latency(config, num_iters, reps=200, warm=20):
                     "D2H of X / F / P" % num_iters}
 
 
+class quiet_stdout:
+    """fd-level silence: KinoDynMP prints from C++ ("Initialized Kino-Dyn planner", the solve times) as the reference does,
+    and the only thing this program may write to stdout is its JSON line"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        self.null = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(self.null, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        os.close(self.null)
+
+
 def kinodyn_latency(reps=(60, 30), warm=5):
     """p50 of the reference's own call, kd.optimize(q, v, N, 1) (abstract_cyclic_gen.py:663; N = 100 there, 10 in the
     benchmark configs), through the drop-in harness SoloMpcGaitGen on one Solo12: the wall time of KinoDynMP.optimize
@@ -159,6 +176,13 @@ def kinodyn_latency(reps=(60, 30), warm=5):
     from bunmpc_amd.cyclic_gen import SoloMpcGaitGen
     model = urdf_model.RobotModel.from_json(open(os.path.join(ROOT, "bunmpc_amd", "robots", "solo12.json")).read())
     q0 = problems.SOLO12_Q0.copy()
+    with quiet_stdout():
+        return _kinodyn_latency(model, q0, reps, warm)
+
+
+def _kinodyn_latency(model, q0, reps, warm):
+    from bunmpc_amd import problems
+    from bunmpc_amd.cyclic_gen import SoloMpcGaitGen
     gg = SoloMpcGaitGen(model, model, np.concatenate([q0, np.zeros(18)]), 0.05, q0)
     import types
     g, ik = problems.TROT, problems.TROT_IK          # motions/cyclic/solo12_trot.py:12-41 as a BiconvexMotionParams-shaped object
@@ -169,15 +193,12 @@ def kinodyn_latency(reps=(60, 30), warm=5):
         state_wt=ik["state_wt"], ctrl_wt=list(ik["ctrl_wt"])), 0.0)
     gg.kd.compute_solve_times()
     out = {"budget_ms": 50.0}
-    import contextlib
-    import io
     for N, n in zip((10, 100), reps):
         ts, tot = [], []
         for r in range(n + warm):
             q, v = q0.copy(), np.zeros(18)
             t0 = time.perf_counter()
-            with contextlib.redirect_stdout(io.StringIO()):        # compute_solve_times prints, as the reference does
-                gg.optimize(q, v, round(0.05 * (r % 10), 3), np.array([0.2, 0.0, 0.0]), 0.0, dyn_iters=N)
+            gg.optimize(q, v, round(0.05 * (r % 10), 3), np.array([0.2, 0.0, 0.0]), 0.0, dyn_iters=N)
             tot.append(time.perf_counter() - t0)
             ts.append(gg.kd.return_solve_times()[2])
         ts, tot = np.array(ts[warm:]) * 1e3, np.array(tot[warm:]) * 1e3
@@ -465,6 +486,11 @@ def main():
                     help="f32: BASELINE config 3's mixed-precision kernel (fp32 iterates, fp64 decisions)")
     args = ap.parse_args()
 
+    # stdout carries the JSON line and nothing else: whatever the legs (or the C++ side of the drop-in classes) print goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -554,8 +580,11 @@ def main():
                                                                       cpu_sample=kd_sample("go2_h60")))
                 if world == 1:
                     out["datagen_pass"] = guarded(lambda: datagen_leg(dev, kd_batch(cfg), args.admm_iters))
+    sys.stdout.flush()
+    os.dup2(json_fd, 1)
+    os.close(json_fd)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

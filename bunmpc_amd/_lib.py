@@ -172,6 +172,8 @@ _SIGS = {
     "bmpc_ik_layout": (None, [_I, _P]),
     "bmpc_ik_layout_trace": (None, [_I, _P, _P, _P]),
     "bmpc_ik_set_profile": (_I, [_I]),
+    "bmpc_ik_set_all_steps": (_I, [_I]),
+    "bmpc_ik_batch_struct_size": (_I, []),
     "bmpc_ik_last_profile": (None, [_P]),
     "bmpc_ik_solve_batch_device": (_I, [_P, _P]),
     "bmpc_ik_centroidal_state_device": (_I, [_P, _P, _P, _I, _P]),
@@ -196,7 +198,7 @@ class IkBatch(C.Structure):
                 [(n, C.c_void_p) for n in ("x0", "dt", "tasks", "state_w", "x_reg", "ctrl_w")] +
                 [("s_state_w", C.c_long), ("s_ctrl_w", C.c_long), ("ws", C.c_void_p), ("active", C.c_void_p),
                  ("iters_run", C.c_void_p), ("s_x_reg", C.c_long), ("sn_state_w", C.c_long), ("sn_x_reg", C.c_long),
-                 ("sn_ctrl_w", C.c_long)])
+                 ("sn_ctrl_w", C.c_long), ("active_list", C.c_void_p)])
 
 
 class KinoDynBatch(C.Structure):
@@ -238,6 +240,8 @@ def lib():
             fn.argtypes = args
         if handle.bmpc_batch_struct_size() != C.sizeof(Batch):
             raise ImportError("bmpc_batch_t layout differs between include/bunmpc.h and bunmpc_amd/_lib.py")
+        if handle.bmpc_ik_batch_struct_size() != C.sizeof(IkBatch):
+            raise ImportError("bmpc_ik_batch_t layout differs between include/bunmpc.h and bunmpc_amd/_lib.py")
         _lib = handle
     return _lib
 

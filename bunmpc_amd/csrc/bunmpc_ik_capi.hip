@@ -148,6 +148,7 @@ bunmpc::IkBatchArgs make_args(int B, int T, int maxiter, const bmpc_model *model
     a.x0 = x0; a.dt = dt; a.tasks = tasks; a.state_w = state_w; a.x_reg = x_reg; a.ctrl_w = ctrl_w;
     a.s_state_w = s_sw; a.s_ctrl_w = s_cw; a.ws = ws; a.active = active;
     a.s_x_reg = bunmpc::kNX; a.sn_state_w = a.sn_x_reg = a.sn_ctrl_w = 0; a.fwd_spec = 0;
+    a.list = nullptr; a.count = nullptr; a.iter = 0; a.n_launch = B;
     return a;
 }
 
@@ -155,6 +156,7 @@ bunmpc::IkBatchArgs make_args(int B, int T, int maxiter, const bmpc_model *model
 // below this many active problems the forward pass runs four step lengths of a problem side by side (one wave per
 // problem: 1024 SIMDs on an MI355X)
 int g_spec_line_search_below = 1024;
+int g_all_steps = 1;              // below a third of that: all ten step lengths at once, three workgroups per problem
 constexpr int kMaxIkCol = 63;     // T + 1 <= 64 nodes: the backward pass computes the gaps one lane per node
 
 // Two host-mapped words and events per (device, stream), through which the kernels' active counter reaches the DDP loop.
@@ -223,8 +225,10 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run) {
     int active = a.B, it = 0, it_end[2] = {0, 0};
     auto enqueue_chunk = [&](int slot) -> int {
         const int chunk = active <= g_spec_line_search_below ? kTailChunk : 1;
-        a.fwd_spec = active <= g_spec_line_search_below / 3 ? 3 : active <= g_spec_line_search_below ? 2 : 0;
+        a.fwd_spec = active <= g_spec_line_search_below / 3 ? (g_all_steps ? 4 : 3) : active <= g_spec_line_search_below ? 2 : 0;
+        a.n_launch = active;        // the host's latest look at the counter: an upper bound of the active list's length
         for (int k = 0; k < chunk && it < a.maxiter; ++k, ++it) {
+            a.iter = it;
             if (int rc = stamp()) return rc;
             HIP_TRY(bunmpc::ik_launch_state(a, st));
             if (int rc = stamp()) return rc;
@@ -404,6 +408,8 @@ void bmpc_ik_last_profile(double *ms5) {
     std::lock_guard<std::mutex> hold(g_profile_lock);
     for (int k = 0; k < 5; ++k) ms5[k] = g_last_profile[k];
 }
+int bmpc_ik_set_all_steps(int on) { const int old = g_all_steps; g_all_steps = on != 0; return old; }
+int bmpc_ik_batch_struct_size(void) { return (int)sizeof(bmpc_ik_batch_t); }
 int bmpc_ik_set_speculative_below(int n_active) { const int old = g_spec_line_search_below; g_spec_line_search_below = n_active; return old; }
 double bmpc_model_total_mass(const bmpc_model_t *m) { return m ? m->host.total_mass : 0.0; }
 
@@ -615,6 +621,7 @@ int bmpc_ik_solve_batch_device(const bmpc_ik_batch_t *d, void *hip_stream) {
                               d->ctrl_w, d->s_ctrl_w, d->ws, d->active);
     a.s_x_reg = d->s_x_reg ? d->s_x_reg : kNX;
     a.sn_state_w = d->sn_state_w; a.sn_x_reg = d->sn_x_reg; a.sn_ctrl_w = d->sn_ctrl_w;
+    if (d->active_list) { a.list = d->active_list; a.count = d->active_list + 2 * (long)d->B; }
     int iters = 0;
     int rc = run_ddp(a, static_cast<hipStream_t>(hip_stream), &iters);
     if (d->iters_run) *d->iters_run = iters;

@@ -116,6 +116,13 @@ __device__ __forceinline__ double node_cost(const RobotModelDev &m, const double
 
 __device__ const double *batch_ptr(const double *p, long stride, long b) { return p + stride * b; }
 
+// problem handled by launch slot `slot` of this DDP iteration: through the active list when there is one (-1: past its end)
+__device__ __forceinline__ long slot_problem(const IkBatchArgs &a, long slot) {
+    if (!a.list) return slot < a.B ? slot : -1;
+    const int cur = a.iter & 1;
+    return slot < a.count[cur] ? (long)a.list[(long)cur * a.B + slot] : -1;
+}
+
 // ------------------------------------------------------------------------------- init ---
 __global__ void ik_init_kernel(const IkBatchArgs a) {
     const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -133,7 +140,9 @@ __global__ void ik_init_kernel(const IkBatchArgs a) {
     double *s = ws + L.scal;
     s[S_COST] = 0; s[S_XREG] = 1e-9; s[S_D1] = 0; s[S_D2] = 0; s[S_STOP] = 0; s[S_FEAS] = 0; s[S_WASFEAS] = 0;
     s[S_DONE] = 0; s[S_ITERS] = 0; s[S_RECALC] = 1; s[S_STATUS] = 0;
-    if (b == 0) *a.active = a.B;
+    ws[L.arrive] = 0.0;          // (read as an unsigned counter)
+    if (a.list) a.list[b] = (int)b;
+    if (b == 0) { *a.active = a.B; if (a.count) { a.count[0] = a.B; a.count[1] = 0; } }
 }
 
 // --------------------------------------------------------------------------- calcDiff ---
@@ -213,9 +222,10 @@ __device__ __forceinline__ double node_state_terms(const IkBatchArgs &a, long b,
 __global__ __launch_bounds__(64) void ik_state_kernel(const IkBatchArgs a) {
     const int nn = a.T + 1;
     const long idx = (long)blockIdx.x * 64 + threadIdx.x;
-    const long b = idx / nn;
+    if (idx == 0 && a.count) a.count[(a.iter + 1) & 1] = 0;     // the list this iteration's forward pass will fill
+    const long b = slot_problem(a, idx / nn);
     const int tw = (int)(idx % nn);
-    if (b >= a.B) return;
+    if (b < 0) return;
     const IkLayout L = IkLayout::make(a.T);
     double *ws = a.ws + b * L.total;
     if (ws[L.scal + S_DONE] != 0.0 || ws[L.scal + S_RECALC] == 0.0) return;
@@ -239,7 +249,8 @@ __global__ __launch_bounds__(64) void ik_state_kernel(const IkBatchArgs a) {
 __global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a) {
     __shared__ CalcLds s;
     const int nn = a.T + 1, groups = (nn + kCalcNodes - 1) / kCalcNodes;
-    const long b = blockIdx.x / groups;
+    const long b = slot_problem(a, blockIdx.x / groups);
+    if (b < 0) return;
     const int t0 = (blockIdx.x % groups) * kCalcNodes, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const IkLayout L = IkLayout::make(a.T);
     double *ws = a.ws + b * L.total;
@@ -546,7 +557,8 @@ __device__ __forceinline__ void apply_FxT(double (&x)[kNDX], unsigned a6_addr, u
 
 __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
     __shared__ BackwardLds s;
-    const long b = blockIdx.x;
+    const long b = slot_problem(a, blockIdx.x);
+    if (b < 0) return;
     const int lane = threadIdx.x;
     const IkLayout L = IkLayout::make(a.T);
     double *ws = a.ws + b * L.total;
@@ -800,7 +812,7 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
 // and the base, one for the state cost, one for the control cost and the Euler step), and pieces with different code
 // cannot overlap inside a wave -- so a wave carries four independent chains through the same instruction stream.
 constexpr int kFwdSub = 4, kFwdLanes = 64 / kFwdSub;
-static_assert(kFwdSub == kTrySlots, "one trial slot per sub-group");
+static_assert(kTrySlots >= 3 * kFwdSub - 2, "one trial slot per step length in the all-step-lengths mapping");
 
 // Every vector a lane reads as a whole is 16-byte aligned and padded to the length of the batch reader that fetches it
 // (lds_batch.h): read element by element, each LDS read waits out its own latency in front of its first use.
@@ -847,8 +859,13 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
     const int lane = threadIdx.x & 63, wave = NW > 1 ? (int)(threadIdx.x >> 6) : 0, si = lane / kFwdLanes, l = lane % kFwdLanes;
     const bool do_chain = NW == 1 || wave == 0, do_cost = NW == 1 || wave == 1, do_reg = NW == 1 || wave == (NW == 2 ? 0 : 2);
     const bool spec = a.fwd_spec != 0;
-    const long b = spec ? (long)blockIdx.x : (long)blockIdx.x * kFwdSub + si;
-    const bool pvalid = b < a.B;
+    // fwd_spec == 4: THREE workgroups per problem, workgroup g trying step lengths 2^-(4g + s): all ten in one round, on
+    // separate CUs (inside one workgroup the register budget of seven waves did not allow it); the last of the
+    // three to finish takes SolverDDP's decision for the problem
+    const bool all10 = NW == 3 && a.fwd_spec == 4;
+    const int grp = all10 ? (int)(blockIdx.x % 3) : 0;
+    const long b = slot_problem(a, all10 ? (long)(blockIdx.x / 3) : spec ? (long)blockIdx.x : (long)blockIdx.x * kFwdSub + si);
+    const bool pvalid = b >= 0;
     const long bb = pvalid ? b : 0;
     const IkLayout L = IkLayout::make(a.T);
     double *ws = a.ws + bb * L.total;
@@ -857,7 +874,8 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
     bool live = pvalid && sc[S_DONE] == 0.0;     // this sub-group still has a line search to do
     if (!__any(live)) return;
     const int T = a.T, nn = a.T + 1;
-    const long xs_try = L.xs_try + (spec ? (long)si * nn * kNX : 0), us_try = L.us_try + (spec ? (long)si * T * kNV : 0);
+    const int tslot = spec ? 4 * grp + si : 0;       // where this sub-group's trial trajectory goes
+    const long xs_try = L.xs_try + (long)tslot * nn * kNX, us_try = L.us_try + (long)tslot * T * kNV;
     {   // the robot model is read many times per node: stage it in LDS once
         const int *src = reinterpret_cast<const int *>(a.model);
         int *dst = reinterpret_cast<int *>(&s.m);
@@ -889,7 +907,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
 #endif
     for (int round = 0; round < 10; ++round) {   // alphas_ = 2^-n, n = 0..9
         if (!__any(live)) break;
-        const int ia = spec ? kFwdSub * round + si : round;
+        const int ia = all10 ? 4 * grp + si : spec ? kFwdSub * round + si : round;
         bool run = live && ia < 10;     // false once this trial has failed (tryStep threw) or there is no step length left
         const double al = ldexp(1.0, -ia);
         if (!spec && live) alpha = al;
@@ -1074,6 +1092,25 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
         }
         if (!spec) {
             if (pass) { accepted = true; live = false; cost_try = ctry; }
+        } else if (all10) {
+            // this workgroup's results to the workspace; the last of the problem's three workgroups to arrive decides
+            if (l == 0 && ia < 10) { ws[L.votes + 2 * ia] = pass ? 1.0 : 0.0; ws[L.votes + 2 * ia + 1] = ctry; }
+            __threadfence();
+            __syncthreads();
+            unsigned *arrive = reinterpret_cast<unsigned *>(ws + L.arrive);
+            if (threadIdx.x == 0) s.vote[0] = atomicAdd(arrive, 1u) == 2u ? 1.0 : 0.0;
+            __syncthreads();
+            if (s.vote[0] == 0.0) return;
+            __threadfence();
+            if (threadIdx.x == 0) *arrive = 0u;
+            int w = -1;
+            for (int k = 9; k >= 0; --k) if (__builtin_nontemporal_load(ws + L.votes + 2 * k) != 0.0) w = k;    // first in SolverDDP's order
+            if (live) {
+                if (w >= 0) { accepted = true; win = w; alpha = ldexp(1.0, -w); cost_try = __builtin_nontemporal_load(ws + L.votes + 2 * w + 1); }
+                else alpha = ldexp(1.0, -9);
+                live = false;
+            }
+            break;
         } else {
             if (l == 0) { s.vote[si] = pass ? 1.0 : 0.0; s.ctry[si] = ctry; }
             __syncthreads();
@@ -1114,6 +1151,10 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
         if (accepted) { sc[S_WASFEAS] = feas ? 1.0 : 0.0; sc[S_FEAS] = 1.0; sc[S_COST] = cost_try; sc[S_RECALC] = 1.0; }
         else sc[S_RECALC] = 0.0;
         sc[S_XREG] = xreg; sc[S_ITERS] = iters;
+        if (!done && a.list) {      // goes on: onto the next iteration's list (the order there is arbitrary; nothing depends on it)
+            const int nxt = (a.iter + 1) & 1;
+            a.list[(long)nxt * a.B + atomicAdd(a.count + nxt, 1)] = (int)b;
+        }
         if (iters <= (double)kTraceIters) {
             double *tr = ws + L.trace + ((long)iters - 1) * kTraceDoubles;
             tr[0] = accepted ? cost_try : cost; tr[1] = xreg; tr[2] = accepted ? alpha : 0.0; tr[3] = sc[S_STOP];
@@ -1184,24 +1225,28 @@ hipError_t ik_launch_init(const IkBatchArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(ik_init_kernel, dim3((a.B + 63) / 64), dim3(64), 0, st, a);
     return hipGetLastError();
 }
+// launches cover the problems of the active list (a.n_launch, the host's last look at the counter, bounds its length)
+static long launch_problems(const IkBatchArgs &a) { return a.list ? (a.n_launch < a.B ? a.n_launch : a.B) : a.B; }
 hipError_t ik_launch_state(const IkBatchArgs &a, hipStream_t st) {
-    const long n = (long)a.B * (a.T + 1);
+    const long n = launch_problems(a) * (a.T + 1);
     hipLaunchKernelGGL(ik_state_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 hipError_t ik_launch_calcdiff(const IkBatchArgs &a, hipStream_t st) {
-    const long n = (long)a.B * ((a.T + 1 + 1) / 2);   // two nodes per workgroup
+    const long n = launch_problems(a) * ((a.T + 1 + 1) / 2);   // two nodes per workgroup
     hipLaunchKernelGGL(ik_calcdiff_kernel, dim3((unsigned)n), dim3(128), 0, st, a);
     return hipGetLastError();
 }
 hipError_t ik_launch_backward(const IkBatchArgs &a, hipStream_t st) {
-    hipLaunchKernelGGL(ik_backward_kernel, dim3(a.B), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(ik_backward_kernel, dim3((unsigned)launch_problems(a)), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 hipError_t ik_launch_forward(const IkBatchArgs &a, hipStream_t st) {
-    if (a.fwd_spec == 3) hipLaunchKernelGGL(ik_forward_kernel<3>, dim3(a.B), dim3(192), 0, st, a);
-    else if (a.fwd_spec) hipLaunchKernelGGL(ik_forward_kernel<2>, dim3(a.B), dim3(128), 0, st, a);
-    else hipLaunchKernelGGL(ik_forward_kernel<1>, dim3((a.B + 3) / 4), dim3(64), 0, st, a);
+    const unsigned n = (unsigned)launch_problems(a);
+    if (a.fwd_spec == 4) hipLaunchKernelGGL(ik_forward_kernel<3>, dim3(3 * n), dim3(192), 0, st, a);
+    else if (a.fwd_spec == 3) hipLaunchKernelGGL(ik_forward_kernel<3>, dim3(n), dim3(192), 0, st, a);
+    else if (a.fwd_spec) hipLaunchKernelGGL(ik_forward_kernel<2>, dim3(n), dim3(128), 0, st, a);
+    else hipLaunchKernelGGL(ik_forward_kernel<1>, dim3((n + 3) / 4), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 hipError_t ik_launch_centroidal_state(const RobotModelDev *model, const double *x, double *out9, int B, hipStream_t st) {

@@ -40,7 +40,7 @@ constexpr int kNodeTaskDoubles = 5 * kFrameSlots + 4 + 7 + 2;
 
 // trial trajectories per problem: slot 0 is the one the sequential line search uses; the speculative line search
 // (four step lengths of one problem at once, ik_forward_kernel) fills all four
-constexpr int kTrySlots = 4;
+constexpr int kTrySlots = 12;    // 10 used by the all-step-lengths mapping (three workgroups of four trials per problem)
 // per-iteration trace of a problem's DDP (telemetry, read back by the parity tests): after iteration i (0-based, i < kTraceIters)
 // [cost, regularisation, accepted step length (0 = none), stopping criterion] as SolverDDP holds them at the end of the iteration
 constexpr int kTraceIters = 128, kTraceDoubles = 4;
@@ -48,7 +48,7 @@ constexpr int kTraceIters = 128, kTraceDoubles = 4;
 // Layout of the per-problem DDP workspace in HBM (doubles), T = number of running nodes.
 struct IkLayout {
     int T;
-    long xs, us, xs_try, us_try, fs, xnext, Lx, Lxx, Lu, Luu, A6, B6, K, kff, Qu, Quuk, scal, nrs, njl, ncs, trace, total;
+    long xs, us, xs_try, us_try, fs, xnext, Lx, Lxx, Lu, Luu, A6, B6, K, kff, Qu, Quuk, scal, nrs, njl, ncs, trace, votes, arrive, total;
     __host__ __device__ static IkLayout make(int T) {
         IkLayout l; l.T = T;
         long o = 0;
@@ -65,6 +65,8 @@ struct IkLayout {
         // per node, written by ik_state_kernel for ik_calcdiff_kernel (bulk iterations): state residual, its Jlog6 block, cost part
         l.nrs = take((long)(T + 1) * kNDX); l.njl = take((long)(T + 1) * 36); l.ncs = take((long)T + 1);
         l.trace = take((long)kTraceIters * kTraceDoubles);
+        // all-step-lengths line search: [pass flag, trial cost] per step length, and the arrival counter of the problem's workgroups
+        l.votes = take(2 * kTrySlots); l.arrive = take(2);
         l.total = o;
         return l;
     }
@@ -75,7 +77,13 @@ enum IkScal { S_COST = 0, S_XREG, S_D1, S_D2, S_STOP, S_FEAS, S_WASFEAS, S_DONE,
 struct IkBatchArgs {
     int B, T, maxiter;
     int fwd_spec;              // forward pass: 0 = four problems per wave; 2 / 3 = one problem per workgroup of 2 / 3 waves,
-                               // four step lengths at once (few active problems)
+                               // four step lengths at once (few active problems); 4 = three such workgroups per problem, all
+                               // ten step lengths at once (very few active problems)
+    // Active-problem list (or null: every launch covers all B problems, finished ones return at once).  Two ping-pong
+    // lists of B problem indices + two counts: DDP iteration k works on list[k & 1][0 .. count[k & 1]) and its forward pass
+    // appends the problems that go on to list[(k + 1) & 1].  n_launch (host side, one look behind) bounds count.
+    int *list, *count;
+    int iter, n_launch;
     const RobotModelDev *model;
     const double *x0;          // [B][37]
     const double *dt;          // [B][T]

@@ -11,7 +11,7 @@ from .inverse_kinematics_cpp import as_device_model
 
 
 class KinoDynDeviceBatch:
-    def __init__(self, wb, model, device="cuda", num_iters=10, maxit=150, ddp_maxiter=100, plan=None):
+    def __init__(self, wb, model, device="cuda", num_iters=10, maxit=150, ddp_maxiter=100, plan=None, use_active_list=True):
         """plan: a plan_batch.DeviceWbPlan whose tensors replace the host-built centroidal inputs and IK task blocks of
         `wb` (weights and regularisation references still come from wb)"""
         import torch
@@ -40,6 +40,7 @@ class KinoDynDeviceBatch:
         self.trace_off, self.trace_iters, self.trace_width = t_off.value, t_it.value, t_w.value
         self.ws = torch.zeros((B, self.ws_doubles), dtype=f64, device=self.device)
         self.active = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.active_list = torch.zeros(2 * B + 2, dtype=torch.int32, device=self.device)
         self.iters_run = C.c_int(0)
         d = _lib.KinoDynBatch()
         C.memmove(C.byref(d.dyn), C.byref(self.dyn.desc), C.sizeof(_lib.Batch))
@@ -50,6 +51,7 @@ class KinoDynDeviceBatch:
         ik.s_state_w = 0 if wb.state_w.shape[0] == 1 else 36
         ik.s_ctrl_w = 0 if wb.ctrl_w.shape[0] == 1 else 18
         ik.ws, ik.active = self.ws.data_ptr(), self.active.data_ptr()
+        ik.active_list = self.active_list.data_ptr() if use_active_list else None
         ik.iters_run = C.addressof(self.iters_run)
         d.x = self.x.data_ptr()
         self.desc = d

@@ -214,7 +214,11 @@ typedef struct {
     int *active;
     int *iters_run;   /* host int or NULL: DDP iterations the loop executed */
     long s_x_reg, sn_state_w, sn_x_reg, sn_ctrl_w;   /* 0 = defaults: x_reg [B][37], one vector per problem */
+    int *active_list; /* device, 2 B + 2 ints of scratch, or NULL.  With it every launch of the DDP loop covers only the problems
+                         still iterating (an index list the forward pass rebuilds each iteration); without it every launch
+                         covers all B and finished problems return at once.  Results do not depend on it. */
 } bmpc_ik_batch_t;
+int bmpc_ik_batch_struct_size(void);     /* sizeof(bmpc_ik_batch_t), to catch binding drift */
 int bmpc_ik_workspace_doubles(int n_col);
 void bmpc_ik_layout(int n_col, long *offsets8);      /* xs, us, scalars, K, k, fs, Lx, Lxx */
 /* telemetry: rows [iteration i < *iters][*width = 4] at *offset of a problem's workspace: cost, regularisation, accepted step
@@ -222,8 +226,11 @@ void bmpc_ik_layout(int n_col, long *offsets8);      /* xs, us, scalars, K, k, f
 void bmpc_ik_layout_trace(int n_col, long *offset, int *iters, int *width);
 /* Line-search scheduling of the batched DDP (no effect on results): while at most n_active problems are still
  * iterating, four step lengths of a problem are tried side by side (one wave per problem) instead of one after the
- * other (four problems per wave).  Default 1024 (one wave per SIMD of an MI355X); 0 = never.  Returns the old value. */
+ * other (four problems per wave); below a third of that, all ten step lengths at once on three workgroups per problem
+ * (bmpc_ik_set_all_steps(0) keeps four at a time).  Default 1024 (one wave per SIMD of an MI355X); 0 = never.  Both return
+ * the old value. */
 int bmpc_ik_set_speculative_below(int n_active);
+int bmpc_ik_set_all_steps(int on);
 int bmpc_ik_solve_batch_device(const bmpc_ik_batch_t *d, void *hip_stream);
 /* Measurement aid (additive): with profiling on, the DDP loop brackets each of its kernels with events; after a batch solve
  * bmpc_ik_last_profile returns the summed milliseconds of ik_state / ik_calcdiff / ik_backward / ik_forward and of the rest

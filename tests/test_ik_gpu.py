@@ -203,24 +203,33 @@ def test_kinodyn_batch_go2_h60(oracle):
 
 
 def test_line_search_scheduling_does_not_change_results(model):
-    """the forward pass tries step lengths one after the other (four problems per wave) or four at a time (one problem
-    per wave); SolverDDP's decision -- the first passing step length in its order -- is the same either way"""
+    """How the batched DDP is scheduled must not show in its results: step lengths one after the other (four problems per
+    wave), four at a time (one problem per workgroup) or all ten at once (three workgroups per problem, the last to arrive
+    decides) -- SolverDDP's decision, the first passing step length in its order, is the same; and launches over the
+    active-problem list or over all B problems touch the same problems."""
     from bunmpc_amd import _lib
     from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
+    lib = _lib.lib()
     wb = problems.make_wb_batch(model, 9)
     out = []
-    old = _lib.lib().bmpc_ik_set_speculative_below(0)
+    old, old_all = lib.bmpc_ik_set_speculative_below(0), lib.bmpc_ik_set_all_steps(1)
     try:
-        for below in (0, 1 << 30):
-            _lib.lib().bmpc_ik_set_speculative_below(below)
-            kb = KinoDynDeviceBatch(wb, model, num_iters=10)
+        for below, all_steps, use_list in ((0, 0, True), (1 << 30, 0, True), (1 << 30, 1, True), (0, 0, False), (1 << 30, 1, False), (6, 1, True)):
+            lib.bmpc_ik_set_speculative_below(below)
+            lib.bmpc_ik_set_all_steps(all_steps)
+            kb = KinoDynDeviceBatch(wb, model, num_iters=10, use_active_list=use_list)
             kb.solve()
             out.append(kb.results())
     finally:
-        _lib.lib().bmpc_ik_set_speculative_below(old)
-    assert np.array_equal(out[0]["ik_iters"], out[1]["ik_iters"]) and np.all(out[0]["ik_status"] == 0)
-    assert np.array_equal(out[0]["xs"], out[1]["xs"]) and np.array_equal(out[0]["us"], out[1]["us"])
-    assert np.array_equal(out[0]["ik_cost"], out[1]["ik_cost"])
+        lib.bmpc_ik_set_speculative_below(old)
+        lib.bmpc_ik_set_all_steps(old_all)
+    assert np.all(out[0]["ik_status"] == 0) and len(set(out[0]["ik_iters"].tolist())) > 1      # problems finish at different iterations
+    for o in out[1:]:
+        assert np.array_equal(out[0]["ik_iters"], o["ik_iters"])
+        assert np.array_equal(out[0]["xs"], o["xs"]) and np.array_equal(out[0]["us"], o["us"])
+        assert np.array_equal(out[0]["ik_cost"], o["ik_cost"])
+        n = int(out[0]["ik_iters"].max())
+        assert np.array_equal(out[0]["ik_trace"][:, :1], o["ik_trace"][:, :1]) and n <= 100
 
 
 def test_ik_longest_horizon(model):
