@@ -156,7 +156,9 @@ bunmpc::IkBatchArgs make_args(int B, int T, int maxiter, const bmpc_model *model
 // below this many active problems the forward pass runs four step lengths of a problem side by side (one wave per
 // problem: 1024 SIMDs on an MI355X)
 int g_spec_line_search_below = 1024;
-int g_all_steps = 1;              // below a third of that: all ten step lengths at once, three workgroups per problem
+int g_all_steps = 0;              // at most this many active problems: all ten step lengths at once, three workgroups per problem
+                                  // (0 = never, the default: measured on the MI355X it gains < 1 % on the Go2 H = 60 batch at <= 85 -- one workgroup of
+                                  // three waves per CU is the forward kernel's residency -- and loses 2 % on Solo12)
 constexpr int kMaxIkCol = 63;     // T + 1 <= 64 nodes: the backward pass computes the gaps one lane per node
 
 // Two host-mapped words and events per (device, stream), through which the kernels' active counter reaches the DDP loop.
@@ -225,7 +227,7 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run) {
     int active = a.B, it = 0, it_end[2] = {0, 0};
     auto enqueue_chunk = [&](int slot) -> int {
         const int chunk = active <= g_spec_line_search_below ? kTailChunk : 1;
-        a.fwd_spec = active <= g_spec_line_search_below / 3 ? (g_all_steps ? 4 : 3) : active <= g_spec_line_search_below ? 2 : 0;
+        a.fwd_spec = active <= g_all_steps ? 4 : active <= g_spec_line_search_below / 3 ? 3 : active <= g_spec_line_search_below ? 2 : 0;
         a.n_launch = active;        // the host's latest look at the counter: an upper bound of the active list's length
         for (int k = 0; k < chunk && it < a.maxiter; ++k, ++it) {
             a.iter = it;
@@ -408,7 +410,7 @@ void bmpc_ik_last_profile(double *ms5) {
     std::lock_guard<std::mutex> hold(g_profile_lock);
     for (int k = 0; k < 5; ++k) ms5[k] = g_last_profile[k];
 }
-int bmpc_ik_set_all_steps(int on) { const int old = g_all_steps; g_all_steps = on != 0; return old; }
+int bmpc_ik_set_all_steps(int n_active) { const int old = g_all_steps; g_all_steps = n_active; return old; }
 int bmpc_ik_batch_struct_size(void) { return (int)sizeof(bmpc_ik_batch_t); }
 int bmpc_ik_set_speculative_below(int n_active) { const int old = g_spec_line_search_below; g_spec_line_search_below = n_active; return old; }
 double bmpc_model_total_mass(const bmpc_model_t *m) { return m ? m->host.total_mass : 0.0; }

@@ -212,9 +212,9 @@ def test_line_search_scheduling_does_not_change_results(model):
     lib = _lib.lib()
     wb = problems.make_wb_batch(model, 9)
     out = []
-    old, old_all = lib.bmpc_ik_set_speculative_below(0), lib.bmpc_ik_set_all_steps(1)
+    old, old_all = lib.bmpc_ik_set_speculative_below(0), lib.bmpc_ik_set_all_steps(0)
     try:
-        for below, all_steps, use_list in ((0, 0, True), (1 << 30, 0, True), (1 << 30, 1, True), (0, 0, False), (1 << 30, 1, False), (6, 1, True)):
+        for below, all_steps, use_list in ((0, 0, True), (1 << 30, 0, True), (1 << 30, 1 << 30, True), (0, 0, False), (1 << 30, 1 << 30, False), (6, 3, True)):
             lib.bmpc_ik_set_speculative_below(below)
             lib.bmpc_ik_set_all_steps(all_steps)
             kb = KinoDynDeviceBatch(wb, model, num_iters=10, use_active_list=use_list)

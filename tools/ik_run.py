@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""two batch solves of KinoDynMP.optimize (the second is the one to look at in a kernel trace), printing the wall time.
+usage: tools/ik_run.py solo12_h20|go2_h60 [B] [spec_below] [all_steps_below]"""
+import dataclasses, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from bunmpc_amd import _lib, problems, urdf_model
+from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
+cfg = sys.argv[1]
+B = int(sys.argv[2]) if len(sys.argv) > 2 else (1024 if cfg == "go2_h60" else 4096)
+lib = _lib.lib()
+if len(sys.argv) > 3:
+    lib.bmpc_ik_set_speculative_below(int(sys.argv[3]))
+if len(sys.argv) > 4:
+    lib.bmpc_ik_set_all_steps(int(sys.argv[4]))
+robot = "go2" if cfg == "go2_h60" else "solo12"
+model = urdf_model.RobotModel.from_json(open(os.path.join(ROOT, "bunmpc_amd", "robots", robot + ".json")).read())
+if cfg == "go2_h60":
+    wb = problems.make_wb_batch(model, B, gait=dataclasses.replace(problems.TROT, nom_ht=0.30, gait_horizon=6.0), wb=problems.GO2_WB)
+else:
+    wb = problems.make_wb_batch(model, B)
+kb = KinoDynDeviceBatch(wb, model, num_iters=10)
+for rep in range(3):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kb.solve()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    kb.solve_ik_only()
+    torch.cuda.synchronize()
+    print("solve %.2f ms, ik only %.2f ms" % ((t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3))
+r = kb.results()
+print("iters mean %.2f max %d not converged %d" % (r["ik_iters"].mean(), r["ik_iters"].max(), (r["ik_status"] != 0).sum()))
