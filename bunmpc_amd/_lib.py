@@ -86,6 +86,7 @@ _P = C.c_void_p
 _SIGS = {
     "bmpc_abi_version": (_I, []),
     "bmpc_batch_struct_size": (_I, []),
+    "bmpc_set_latency_mapping_max_batch": (_I, [_I]),
     "bmpc_last_error": (C.c_char_p, []),
     "bmpc_device_count": (_I, [_P]),
     "bmpc_set_device": (_I, [_I]),

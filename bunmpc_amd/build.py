@@ -15,8 +15,8 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
-SOURCES = ["biconvex_admm.hip", "bunmpc_capi.hip", "ik_ddp.hip", "bunmpc_ik_capi.hip", "plan_gen.hip", "id_ctrl.hip", "perturb.hip"]
-HEADERS = [os.path.join(CSRC, h) for h in ("biconvex_kernels.h", "ik_types.h", "rbd_device.h", "rbd_quad.h", "lds_batch.h", "id_types.h", "perturb_types.h")] + \
+SOURCES = ["biconvex_admm.hip", "biconvex_latency.hip", "bunmpc_capi.hip", "ik_ddp.hip", "bunmpc_ik_capi.hip", "plan_gen.hip", "id_ctrl.hip", "perturb.hip"]
+HEADERS = [os.path.join(CSRC, h) for h in ("biconvex_kernels.h", "biconvex_lanes.h", "ik_types.h", "rbd_device.h", "rbd_quad.h", "lds_batch.h", "id_types.h", "perturb_types.h")] + \
           [os.path.join(os.path.dirname(_HERE), "include", "bunmpc.h")]
 LIB = os.path.join(_HERE, "libbunmpc_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

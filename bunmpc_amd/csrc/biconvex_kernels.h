@@ -56,6 +56,12 @@ constexpr int kMaxKnots = 64;  // H + 1 <= 64: one knot per lane, one problem pe
 // hipErrorInvalidValue for unsupported shapes (n_eff != 4, H + 1 > 64).
 hipError_t launch_biconvex_admm(const BatchArgs &a, int n_eff, hipStream_t stream);
 
+// The one-problem-per-wave mapping (biconvex_latency.hip): fp64, n_eff = 4, H + 1 <= 21.  launch_biconvex_admm takes it for
+// batches of at most latency_mapping_max_batch() problems that fit.
+bool latency_mapping_fits(const BatchArgs &a, int n_eff);
+hipError_t launch_biconvex_latency(const BatchArgs &a, hipStream_t stream);
+int set_latency_mapping_max_batch(int max_batch);   // returns the old value
+
 // Lane-exchange self test (DPP shifts and segment sums used by the kernel).
 // out must hold 6*64 doubles.
 hipError_t launch_lane_selftest(const double *in, double *out, hipStream_t stream);

@@ -1,0 +1,126 @@
+// Lane-level helpers shared by the centroidal ADMM kernels (biconvex_admm.hip: one knot per lane, batch throughput;
+// biconvex_latency.hip: one problem per wave, knots x component groups across the lanes).  Included inside each translation
+// unit's anonymous namespace.
+#pragma once
+
+#define UNROLL _Pragma("unroll")
+
+// DPP controls (LLVM SIDefines.h DppCtrl)
+constexpr int DPP_QUAD_XOR1 = 0xB1;     // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;     // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int DPP_ROW_MIRROR = 0x140;
+constexpr int DPP_WAVE_SHL1 = 0x130;    // lane i <- lane i+1
+constexpr int DPP_WAVE_SHR1 = 0x138;    // lane i <- lane i-1
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    // bound_ctrl:1 -- a lane without a source lane reads 0, so no destination pre-initialisation
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// value held by the previous / next knot's lane (0 at the wave ends)
+template <typename R> __device__ __forceinline__ R from_prev(R v) { return dpp_mov<DPP_WAVE_SHR1>(v); }
+template <typename R> __device__ __forceinline__ R from_next(R v) { return dpp_mov<DPP_WAVE_SHL1>(v); }
+
+__device__ __forceinline__ double swap16_sum(double v) {
+    unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+__device__ __forceinline__ double swap32_sum(double v) {
+    unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+
+// Sum over the LPP-lane segment, result in every lane of it (fixed butterfly order,
+// so all lanes hold the same bits).
+template <int LPP>
+__device__ __forceinline__ double seg_sum(double v) {
+    v += dpp_mov<DPP_QUAD_XOR1>(v);
+    v += dpp_mov<DPP_QUAD_XOR2>(v);
+    v += dpp_mov<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_mov<DPP_ROW_MIRROR>(v);
+    if (LPP >= 32) v = swap16_sum(v);
+    if (LPP >= 64) v = swap32_sum(v);
+    return v;
+}
+
+// Two segment sums at once, step by step: the steps of one butterfly depend on each other (and a DPP move may not follow the
+// write of its source by less than two cycles), so two sums issued one after the other cost two full dependency chains; issued
+// side by side each hides the other's waits.  Same order of additions per sum as seg_sum, hence the same bits.
+template <int LPP>
+__device__ __forceinline__ void seg_sum2(double &a, double &b) {
+    double ta, tb;
+    ta = dpp_mov<DPP_QUAD_XOR1>(a); tb = dpp_mov<DPP_QUAD_XOR1>(b); a += ta; b += tb;
+    ta = dpp_mov<DPP_QUAD_XOR2>(a); tb = dpp_mov<DPP_QUAD_XOR2>(b); a += ta; b += tb;
+    ta = dpp_mov<DPP_ROW_HALF_MIRROR>(a); tb = dpp_mov<DPP_ROW_HALF_MIRROR>(b); a += ta; b += tb;
+    ta = dpp_mov<DPP_ROW_MIRROR>(a); tb = dpp_mov<DPP_ROW_MIRROR>(b); a += ta; b += tb;
+    if (LPP >= 32) {
+        unsigned al = __double2loint(a), ah = __double2hiint(a), bl = __double2loint(b), bh = __double2hiint(b);
+        auto x0 = __builtin_amdgcn_permlane16_swap(al, al, false, false);
+        auto x1 = __builtin_amdgcn_permlane16_swap(ah, ah, false, false);
+        auto y0 = __builtin_amdgcn_permlane16_swap(bl, bl, false, false);
+        auto y1 = __builtin_amdgcn_permlane16_swap(bh, bh, false, false);
+        a = __hiloint2double(x1[0], x0[0]) + __hiloint2double(x1[1], x0[1]);
+        b = __hiloint2double(y1[0], y0[0]) + __hiloint2double(y1[1], y0[1]);
+    }
+    if (LPP >= 64) {
+        unsigned al = __double2loint(a), ah = __double2hiint(a), bl = __double2loint(b), bh = __double2hiint(b);
+        auto x0 = __builtin_amdgcn_permlane32_swap(al, al, false, false);
+        auto x1 = __builtin_amdgcn_permlane32_swap(ah, ah, false, false);
+        auto y0 = __builtin_amdgcn_permlane32_swap(bl, bl, false, false);
+        auto y1 = __builtin_amdgcn_permlane32_swap(bh, bh, false, false);
+        a = __hiloint2double(x1[0], x0[0]) + __hiloint2double(x1[1], x0[1]);
+        b = __hiloint2double(y1[0], y0[0]) + __hiloint2double(y1[1], y0[1]);
+    }
+}
+
+// HBM holds fp64 whatever the arithmetic type R of the kernel; conversion happens at the load / store
+template <typename R> __device__ __forceinline__ R ldz(const double *p, long i, bool ok) { return ok ? (R)p[i] : R(0); }
+
+// v where m is all ones, +0.0 where m is 0 -- two v_and_b32, no branch, and (unlike a multiply by
+// 0/1) it also wipes NaN/inf, which keeps a diverged problem from leaking into its wave-mate
+__device__ __forceinline__ double keep_if(double v, int m) {
+    return __hiloint2double(__double2hiint(v) & m, __double2loint(v) & m);
+}
+__device__ __forceinline__ float keep_if(float v, int m) { return __int_as_float(__float_as_int(v) & m); }
+
+// a / b to ~1 ulp without the IEEE division sequence: v_rcp_f64 (2^-26 or better) + two Newton
+// steps + one residual correction.  Used only inside the cone branch of the projection.
+__device__ __forceinline__ double fast_div(double a, double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+__device__ __forceinline__ float fast_div(float a, float b) { return a / b; }
+
+// type-exact fma / min / max (the unsuffixed C names would promote float operands to double)
+__device__ __forceinline__ double fmaR(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fmaR(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fmaxR(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ float fmaxR(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double fminR(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ float fminR(float a, float b) { return __builtin_fminf(a, b); }
+
+constexpr double kGravity = 9.81;  // centroidal.cpp:63
+
+// Control state of the FISTA / ADMM loops (which problems of the wave still iterate, which are retrying a step, which have
+// finished) is carried as 64-bit LANE MASKS in scalar registers: every decision comes out of a v_cmp as such a mask anyway,
+// combining them is scalar-unit work, and `lanes(m)` turns a mask back into a per-lane predicate (selects and branches take
+// the mask as it is).  As per-lane bools across loop iterations the compiler kept them as 0 / 1 in vector registers: a
+// dozen vector instructions per iteration of pure bookkeeping in an issue-bound kernel.
+typedef unsigned long long mask_t;
+__device__ __forceinline__ bool lanes(mask_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+

@@ -144,6 +144,11 @@ void bmpc_batch_defaults(bmpc_batch_t *d);
 int bmpc_biconvex_solve_batch_device(const bmpc_batch_t *d, void *hip_stream);
 /* all pointers are HOST pointers; copies in, solves, copies out, synchronises */
 int bmpc_biconvex_solve_batch_host(const bmpc_batch_t *d);
+/* Kernel selection (no effect on the discrete path; values equal to rounding): batches of at most max_batch problems with
+ * n_col + 1 <= 21 knots in fp64 are solved ONE PROBLEM PER WAVE (knots x component groups across the lanes: the dependent
+ * chain of a solve is ~2.3x shorter), larger ones one knot per lane with 4 / 2 / 1 problems per wave.  Default 1024 (one
+ * wave per SIMD of an MI355X); 0 = never.  Returns the old value. */
+int bmpc_set_latency_mapping_max_batch(int max_batch);
 /* symbol-name prefix of the kernel that serves (n_col, raw), for profiles */
 const char *bmpc_biconvex_kernel_name(int n_col, int raw);
 

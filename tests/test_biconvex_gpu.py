@@ -23,11 +23,12 @@ def test_lane_exchange_selftest(hiplib):
 
 @pytest.mark.parametrize("config,B,iters", [("solo12_trot_nominal", 1, 10), ("solo12_trot", 16, 10),
                                             ("solo12_mixed", 12, 1), ("go2_bound", 6, 2)])
-def test_batch_matches_oracle(oracle, config, B, iters):
+def test_batch_matches_oracle(oracle, mapping, config, B, iters):
     """Runs that stay out of the chaotic regime described in test_chaotic_envelope (trot at the
     benchmark's 10 ADMM iterations; bound / pace / Go2 over their first 1-2): GPU within 1e-5
     rel-L2 of the strict CPU restatement (measured ~1e-15) and on the identical discrete path
     (iteration and retry counts)."""
+    mapping("batch")
     b = problems.make_batch(config, B)
     ref = oracle.solve_batch(b, num_iters=iters)
     got = bb.solve_host(b, num_iters=iters)
@@ -147,8 +148,10 @@ def test_handle_state_persists_between_solves(oracle):
     assert mp.step_constants() == (r2["L_x"], r2["L_f"])
 
 
-def test_raw_form_with_backtracking(oracle):
+@pytest.mark.parametrize("which", ["batch", "wave"])
+def test_raw_form_with_backtracking(oracle, mapping, which):
     """raw cost/bound arrays + warm start + per-problem L0 (forces retries in both FISTA loops)."""
+    mapping(which)
     b = problems.make_batch("solo12_trot", 6)
     pre = oracle.solve_batch(b, num_iters=0)
     raw = {k: pre[k] for k in ("Qx", "qx", "lbx", "ubx", "Qf")}
@@ -168,9 +171,10 @@ def test_raw_form_with_backtracking(oracle):
 
 
 @pytest.mark.parametrize("H", [3, 15, 16, 31, 32, 63])
-def test_horizons_and_ragged_batches(oracle, H):
-    """All three lane layouts (16/32/64 lanes per problem), the H+1 == lanes edge, and batch
+def test_horizons_and_ragged_batches(oracle, mapping, H):
+    """All three lane layouts (16/32/64 lanes per problem) of the one-knot-per-lane kernel, the H+1 == lanes edge, and batch
     sizes that do not fill the last wave."""
+    mapping("batch")
     B = 7
     b = problems.make_batch("solo12_trot", B, H=H)
     iters = 2 if H < 40 else 1       # long horizons enter the chaotic regime (test_chaotic_envelope) sooner
@@ -193,9 +197,11 @@ def test_unsupported_shapes_are_refused():
     assert bb.solve_host(problems.make_batch("solo12_trot", 1).slice(0, 0), num_iters=1)["X"].shape[0] == 0
 
 
-def test_diverging_problem_does_not_poison_neighbours(oracle):
+@pytest.mark.parametrize("which", ["batch", "wave"])
+def test_diverging_problem_does_not_poison_neighbours(oracle, mapping, which):
     """NaN handling (biconvex.cpp:106-109): a problem that blows up reports status 2 and NaNs;
     the problem sharing its wave is bit-for-bit what it is when solved without that neighbour."""
+    mapping(which)
     b = problems.make_batch("solo12_trot", 4)
     bad = problems.make_batch("solo12_trot", 4)
     bad.x_init[1, 2] = 1e200                      # overflow -> inf/NaN in the first gradient
@@ -212,8 +218,10 @@ def test_diverging_problem_does_not_poison_neighbours(oracle):
     assert ref["stats"][0, 5] == 2 and ref["stats"][0, 0] == 1
 
 
-def test_early_exit_on_exit_tol(oracle):
+@pytest.mark.parametrize("which", ["batch", "wave"])
+def test_early_exit_on_exit_tol(oracle, mapping, which):
     """||A_f X - b_f|| < exit_tol stops a problem (biconvex.cpp:111-114) while its wave-mate goes on."""
+    mapping(which)
     b = problems.make_batch("solo12_trot", 2)
     ref = oracle.solve_batch(b, num_iters=12, exit_tol=0.06)
     got = bb.solve_host(b, num_iters=12, exit_tol=0.06)
@@ -289,3 +297,83 @@ def test_fp32_variant_with_fp64_residual_check(oracle, config, B, H):
     with pytest.raises(_lib.BmpcError) as e:
         bb.solve_host(b, num_iters=1, precision="f32", raw=raw)
     assert e.value.code == 1
+
+
+@pytest.fixture
+def mapping(hiplib):
+    """selects the kernel: 'batch' = one knot per lane (biconvex_admm.hip), 'wave' = one problem per wave (biconvex_latency.hip)"""
+    old = hiplib.bmpc_set_latency_mapping_max_batch(0)
+
+    def choose(which):
+        hiplib.bmpc_set_latency_mapping_max_batch({"batch": 0, "wave": 1 << 30}[which])
+    yield choose
+    hiplib.bmpc_set_latency_mapping_max_batch(old)
+
+
+@pytest.mark.parametrize("config,B,H,iters", [("solo12_trot", 16, None, 10), ("solo12_trot_nominal", 1, None, 10), ("solo12_mixed", 12, None, 1),
+                                              ("solo12_trot", 7, 3, 2), ("solo12_trot", 5, 15, 2), ("solo12_trot", 3, 19, 3)])
+def test_latency_mapping_equals_batch_mapping_and_oracle(oracle, mapping, config, B, H, iters):
+    """The one-problem-per-wave kernel (small batches, H <= 20) against the one-knot-per-lane kernel and the CPU oracle:
+    identical discrete path (every iteration / retry count), values equal to rounding (its segment sums run over another
+    lane order), 1e-5 to the oracle (measured ~1e-15)."""
+    b = problems.make_batch(config, B, H=H) if H else problems.make_batch(config, B)
+    ref = oracle.solve_batch(b, num_iters=iters)
+    mapping("batch")
+    kb = bb.solve_host(b, num_iters=iters, keep_hist=True)
+    mapping("wave")
+    kw = bb.solve_host(b, num_iters=iters, keep_hist=True)
+    assert np.array_equal(kw["stats"], ref["stats"]) and np.array_equal(kw["stats"], kb["stats"])
+    for k in "XFP":
+        assert np.all(rel_l2(kw[k], ref[k]) < TOL), k
+        assert np.all(rel_l2(kw[k], kb[k]) < 1e-12), k
+    assert np.allclose(kw["hist"], kb["hist"], rtol=1e-10, equal_nan=True) and np.allclose(kw["dyn_viol"], kb["dyn_viol"], rtol=1e-10)
+    assert np.array_equal(kw["L_x"], kb["L_x"]) and np.array_equal(kw["L_f"], kb["L_f"])
+
+
+def test_latency_mapping_raw_form_warm_start_and_backtracking(oracle, mapping):
+    """raw cost / bound arrays, warm start, per-problem L0 low enough to force retries in both FISTA loops, early exit, and a
+    diverging problem -- all through the one-problem-per-wave kernel"""
+    mapping("wave")
+    b = problems.make_batch("solo12_trot", 6)
+    pre = oracle.solve_batch(b, num_iters=0)
+    raw = {k: pre[k] for k in ("Qx", "qx", "lbx", "ubx", "Qf")}
+    raw["qf"] = 0.01 * np.random.default_rng(0).standard_normal(pre["Qf"].shape)
+    Lx = np.array([2.25e6, 1e4, 1e5, 3e5, 2.25e6, 5e4])
+    Lf = np.array([506.25, 10.0, 50.0, 506.25, 20.0, 100.0])
+    X0, F0, P0 = b.warm_start()
+    got = bb.solve_host(b, num_iters=3, raw=raw, warm=(X0, F0, P0), L_x=Lx, L_f=Lf)
+    for i in range(b.B):
+        r = oracle.biconvex_solve(b.cnt_plan[i], b.dt[i], b.m, b.x_init[i], pre["Qx"][i], pre["qx"][i], pre["Qf"][i], pre["lbx"][i],
+                                  pre["ubx"][i], X0[i], F0[i], P0[i], L_x=Lx[i], L_f=Lf[i], rho=b.rho, num_iters=3, qf=raw["qf"][i])
+        assert np.array_equal(got["stats"][i], r["stats"]), i
+        assert got["L_x"][i] == r["L_x"] and got["L_f"][i] == r["L_f"]
+        for k in "XFP":
+            assert rel_l2(got[k][i], r[k]) < TOL, (i, k)
+    assert got["stats"][:, 3].sum() > 0 and got["stats"][:, 4].sum() > 0
+    # early exit on exit_tol, different ADMM counts inside one launch
+    b2 = problems.make_batch("solo12_trot", 2)
+    ref = oracle.solve_batch(b2, num_iters=12, exit_tol=0.06)
+    g2 = bb.solve_host(b2, num_iters=12, exit_tol=0.06)
+    assert np.array_equal(g2["stats"], ref["stats"]) and len(set(ref["stats"][:, 0])) > 1
+    # NaN handling (biconvex.cpp:106-109)
+    bad = problems.make_batch("solo12_trot", 3)
+    bad.x_init[1, 2] = 1e200
+    bad.X_nom[1] = 1e200
+    g3 = bb.solve_host(bad, num_iters=4)
+    assert g3["stats"][1, 5] == 2 and g3["stats"][1, 0] == 1 and not np.isfinite(g3["X"][1]).all()
+    assert np.all(g3["stats"][[0, 2], 5] == 0) and np.isfinite(g3["X"][[0, 2]]).all()
+
+
+def test_both_mappings_at_full_size(oracle, mapping):
+    """B = 4096 through both kernels: same iteration statistics for every problem, values equal to rounding"""
+    b = problems.make_batch("solo12_trot", 4096)
+    out = {}
+    for which in ("batch", "wave"):
+        mapping(which)
+        dev = bb.DeviceBatch(b, num_iters=10)
+        dev.solve()
+        out[which] = dev.results()
+    assert np.array_equal(out["batch"]["stats"], out["wave"]["stats"])
+    e = np.maximum(rel_l2(out["wave"]["X"], out["batch"]["X"]), rel_l2(out["wave"]["F"], out["batch"]["F"]))
+    print("wave vs batch mapping over 4096 problems: median %.2e, max %.2e, above 1e-9: %d" % (np.median(e), e.max(), (e > 1e-9).sum()))
+    assert np.median(e) < 1e-13 and (e > 1e-9).mean() < 0.02 and e.max() < 1e-3      # a few problems sit in the chaotic regime (tests/util.py)
