@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""gpurun_out/{bench_<tag>.json, prof_<tag>/, pmc_<tag>_*} (tools/prof_round2.sh) -> profiles/<rnd>_* and profiles/pmc_traffic.json.
+usage: python tools/collect_round2.py <tag> <rnd, e.g. r02>"""
+import collections, csv, glob, json, re, shutil, sys
+
+tag, rnd = sys.argv[1], sys.argv[2]
+bench = json.load(open("gpurun_out/bench_%s.json" % tag))
+shutil.copy("gpurun_out/bench_%s.json" % tag, "profiles/%s_bench.json" % rnd)
+stats = glob.glob("gpurun_out/prof_%s/**/*kernel_stats.csv" % tag, recursive=True)[0]
+rows = list(csv.DictReader(open(stats)))
+keep = [r for r in rows if "bunmpc" in r["Name"] or "copyBuffer" in r["Name"]]
+with open("profiles/%s_bench_kernel_stats.csv" % rnd, "w") as f:
+    w = csv.DictWriter(f, fieldnames=rows[0].keys())
+    w.writeheader()
+    w.writerows(keep)
+trace = list(csv.DictReader(open(glob.glob("gpurun_out/prof_%s/**/*kernel_trace.csv" % tag, recursive=True)[0])))
+name = "biconvex_admm_kernel<double, 32, 4, false, false>"
+h = sorted((r for r in trace if name in r["Kernel_Name"] and int(r["Grid_Size_X"]) == 2048 * 64), key=lambda r: int(r["Start_Timestamp"]))
+n_warm, n_timed = bench["warmup"], bench["steps"]
+d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in h]
+with open("profiles/%s_bench_headline_launches.csv" % rnd, "w") as f:
+    f.write("launch,role,Kernel_Name,Grid_Size_X,Workgroup_Size_X,Start_Timestamp,End_Timestamp,duration_us\n")
+    for i, r in enumerate(h[:n_warm + n_timed]):
+        f.write('%d,%s,"%s",%s,%s,%s,%s,%.3f\n' % (i, "warmup" if i < n_warm else "timed", r["Kernel_Name"], r["Grid_Size_X"], r["Workgroup_Size_X"],
+                                                  r["Start_Timestamp"], r["End_Timestamp"], d[i]))
+timed = d[n_warm:n_warm + n_timed]
+print("headline kernel: %d timed launches, mean %.1f us (bench.py's events: %.1f us)" % (len(timed), sum(timed) / len(timed), bench["roofline"]["kernel_ms"] * 1e3))
+
+# HBM traffic per solve, per kernel
+traffic = json.load(open("profiles/pmc_traffic.json"))
+lines = []
+keys = {"biconvex": "solo12_trot H=20 B=4096 admm_iters=10 fista_maxit=150 f64",
+        "solo12_h20": "kinodyn solo12_h20 H=20 H_ik=10 B=4096 admm_iters=10", "go2_h60": "kinodyn go2_h60 H=60 H_ik=30 B=1024 admm_iters=10"}
+for w, key in keys.items():
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    solves = 3
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = glob.glob("gpurun_out/pmc_%s_%s_%s/**/*counter_collection.csv" % (tag, w, c), recursive=True)[0]
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == c and "bunmpc" in r["Kernel_Name"]:
+                k = re.search(r"(\w+_kernel(<[^>]*>)?)", r["Kernel_Name"]).group(1)
+                per[k][c] += float(r["Counter_Value"])
+    kern = {}
+    tot_f = tot_w = 0.0
+    for k, v in sorted(per.items()):
+        fk, wk = v["FETCH_SIZE"] / solves, v["WRITE_SIZE"] / solves          # KB per solve
+        kern[k] = {"fetch_size_kb_raw": round(fk, 1), "write_size_kb": round(wk, 1), "traffic_bytes": int((2 * fk + wk) * 1024)}
+        tot_f += fk
+        tot_w += wk
+        lines.append("%-12s %-34s FETCH_SIZE %12.1f KB raw (x2 = %12.1f KB)  WRITE_SIZE %12.1f KB   per batch solve" % (w, k[:34], fk, 2 * fk, wk))
+    traffic[key] = {"fetch_size_kb_raw": round(tot_f, 1), "write_size_kb": round(tot_w, 1), "traffic_bytes": int((2 * tot_f + tot_w) * 1024),
+                    "per_kernel": kern, "raw_log": "%s_pmc_hbm.txt" % rnd,
+                    "note": "sums over all launches of one batch solve (3 solves measured, divided by 3); FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950"}
+    if w == "biconvex":
+        k0 = [k for k in kern if "biconvex" in k][0]
+        traffic[key].update(kernel="biconvex_admm_kernel<double, 32, 4, false, false>", algorithmic_bytes=37912576, traffic_bytes=kern[k0]["traffic_bytes"],
+                            fetch_size_kb_raw=kern[k0]["fetch_size_kb_raw"], write_size_kb=kern[k0]["write_size_kb"])
+    lines.append("%-12s TOTAL traffic per batch solve: %.1f MB" % (w, traffic[key]["traffic_bytes"] / 1e6))
+open("profiles/%s_pmc_hbm.txt" % rnd, "w").write("\n".join(lines) + "\n")
+json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1)
+shutil.copy("gpurun_out/pmc_%s_sq.txt" % tag, "profiles/%s_pmc_sq.txt" % rnd)
+print("\n".join(lines))

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""one warm-up + N timed batch solves of a bench workload, nothing else (the program rocprofv3's counter passes run).
+usage: tools/pmc_workload.py biconvex|solo12_h20|go2_h60 [N=2]"""
+import dataclasses, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from bunmpc_amd import batch as bb, problems, urdf_model
+what, N = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 2
+if what == "biconvex":
+    job = bb.DeviceBatch(problems.make_batch("solo12_trot", 4096), num_iters=10).solve
+else:
+    from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
+    robot = "go2" if what == "go2_h60" else "solo12"
+    model = urdf_model.RobotModel.from_json(open(os.path.join(ROOT, "bunmpc_amd", "robots", robot + ".json")).read())
+    if what == "go2_h60":
+        wb = problems.make_wb_batch(model, 1024, gait=dataclasses.replace(problems.TROT, nom_ht=0.30, gait_horizon=6.0), wb=problems.GO2_WB)
+    else:
+        wb = problems.make_wb_batch(model, 4096)
+    job = KinoDynDeviceBatch(wb, model, num_iters=10).solve
+for _ in range(N + 1):
+    job()
+torch.cuda.synchronize()
+print("solves", N + 1)
