@@ -172,6 +172,7 @@ _SIGS = {
     "bmpc_ik_workspace_doubles": (_I, [_I]),
     "bmpc_ik_layout": (None, [_I, _P]),
     "bmpc_ik_layout_trace": (None, [_I, _P, _P, _P]),
+    "bmpc_ik_selftest_state_ops": (_I, [_P, _P, _P, _I, _P, _P, _P, _P]),
     "bmpc_ik_set_profile": (_I, [_I]),
     "bmpc_ik_set_all_steps": (_I, [_I]),
     "bmpc_ik_batch_struct_size": (_I, []),

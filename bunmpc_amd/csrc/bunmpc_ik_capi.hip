@@ -410,6 +410,26 @@ void bmpc_ik_last_profile(double *ms5) {
     std::lock_guard<std::mutex> hold(g_profile_lock);
     for (int k = 0; k < 5; ++k) ms5[k] = g_last_profile[k];
 }
+// self test of the state operators (host arrays): x0, x1 [n][37], dx [n][36] -> diff(x0, x1) and x0 (+) dx by the quaternion
+// versions the forward pass uses (dq, iq) and by the rotation-matrix versions (dr, ir)
+int bmpc_ik_selftest_state_ops(const double *x0, const double *x1, const double *dx, int n, double *dq, double *dr, double *iq, double *ir) {
+    using namespace bunmpc;
+    if (!x0 || !x1 || !dx || !dq || !dr || !iq || !ir || n < 1) return ik_fail(BMPC_BAD_ARG, "bad selftest arguments");
+    Dev in, out;
+    const size_t nx = (size_t)n * kNX, nd = (size_t)n * kNDX;
+    HIP_TRY(in.ensure(sizeof(double) * (2 * nx + nd)));
+    HIP_TRY(out.ensure(sizeof(double) * (2 * nx + 2 * nd)));
+    HIP_TRY(hipMemcpy(in.d(), x0, sizeof(double) * nx, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(in.d() + nx, x1, sizeof(double) * nx, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(in.d() + 2 * nx, dx, sizeof(double) * nd, hipMemcpyHostToDevice));
+    HIP_TRY(ik_launch_state_ops_selftest(in.d(), in.d() + nx, in.d() + 2 * nx, n, out.d(), out.d() + nd, out.d() + 2 * nd, out.d() + 2 * nd + nx, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(dq, out.d(), sizeof(double) * nd, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dr, out.d() + nd, sizeof(double) * nd, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(iq, out.d() + 2 * nd, sizeof(double) * nx, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ir, out.d() + 2 * nd + nx, sizeof(double) * nx, hipMemcpyDeviceToHost));
+    return BMPC_OK;
+}
 int bmpc_ik_set_all_steps(int n_active) { const int old = g_all_steps; g_all_steps = n_active; return old; }
 int bmpc_ik_batch_struct_size(void) { return (int)sizeof(bmpc_ik_batch_t); }
 int bmpc_ik_set_speculative_below(int n_active) { const int old = g_spec_line_search_below; g_spec_line_search_below = n_active; return old; }

@@ -84,7 +84,7 @@ __device__ __forceinline__ void euler_step(const double *x, const double *u, dou
     double dx[kNDX];
     const double *v = x + kNQ;
     UNROLL_RBD for (int i = 0; i < kNV; ++i) { dx[i] = v[i] * dt + u[i] * dt * dt; dx[kNV + i] = u[i] * dt; }
-    state_integrate(x, dx, xnext);
+    if (JAC) state_integrate(x, dx, xnext); else state_integrate_q(x, dx, xnext);
     if (JAC) {
         double dR[9], dp[3];
         exp6(dx, dR, dp);
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
                 double d[kNDX];
                 const double *xa = ws + L.xs + (long)lane * kNX;
                 const double *xb = lane == 0 ? a.x0 + b * kNX : ws + L.xnext + (long)(lane - 1) * kNX;
-                state_diff<false>(xa, xb, d, nullptr);
+                state_diff_q(xa, xb, d);
                 UNROLL_RBD for (int i = 0; i < kNDX; ++i) { ws[L.fs + (long)lane * kNDX + i] = d[i]; mx = fmax(mx, fabs(d[i])); }
             }
             feas = !__any(!(mx < 1e-16));       // th_gaptol_
@@ -953,7 +953,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
                 double d[kNDX], xa[40], xb[40];
                 lds_read_vec40(want_dx ? q.xs : x_reg, xa);
                 lds_read_vec40(q.x, xb);
-                state_diff<false>(xa, xb, d, nullptr);
+                state_diff_q(xa, xb, d);
                 if (want_dx) { UNROLL_RBD for (int i = 0; i < kNDX; ++i) q.dx[i] = d[i]; }
                 else {
                     double acc = 0.0, swv[kNDX];
@@ -963,8 +963,25 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
                 }
             } else if (run && do_reg && l == 5) q.bc[2] = 0.0;
             FSTAMP(0)
-            // phase 2 (needs x only): legs on lanes 0..3, base body on lane 4
-            if (run && do_cost && l <= kLegs) {
+            // phase 2 (needs x only): the robot walk.  With a wave of its own (NW > 1) on all 16 lanes of the sub-group -- lane
+            // 4 leg + j takes joint j of the leg, lane 3 the base body (rbd_quad.h::quad_part16); on the shared wave of the
+            // many-problems mapping legs on lanes 0..3, base body on lane 4
+            if (NW > 1) {
+                if (run && do_cost) {
+                    int fid[kFrameSlots];
+                    UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) fid[f] = tk.frame_w(f) != 0.0 ? tk.frame_id(f) : -1;
+                    PartSum ps;
+                    quad_part16(m, q.x, fid, l, ps);
+                    const int row = l == 3 ? kLegs : ((l & 3) == 0 ? (l >> 2) : -1);
+                    if (row >= 0) {
+                        q.part[row][0] = ps.mass;
+                        UNROLL_RBD for (int c = 0; c < 3; ++c) q.part[row][1 + c] = ps.h1[c];
+                        UNROLL_RBD for (int c = 0; c < 6; ++c) q.part[row][4 + c] = ps.hO[c];
+                        UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
+                            UNROLL_RBD for (int c = 0; c < 3; ++c) q.part[row][10 + 3 * f + c] = ps.fhit[f] ? ps.fx[f][c] : 0.0;
+                    }
+                }
+            } else if (run && do_cost && l <= kLegs) {
                 int fid[kFrameSlots];
                 UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) fid[f] = tk.frame_w(f) != 0.0 ? tk.frame_id(f) : -1;
                 PartSum ps;
@@ -1187,6 +1204,24 @@ __global__ void ik_com_mom_kernel(const RobotModelDev *model, const double *xs, 
     for (int c = 0; c < 6; ++c) mom[i * 6 + c] = p1.hg[c];
 }
 
+// both versions of the state operators on n samples (tests/test_rbd_gpu.py)
+__global__ void ik_state_ops_selftest_kernel(const double *x0, const double *x1, const double *dx, int n, double *dq, double *dr, double *iq, double *ir) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a[kNX], b[kNX], d[kNDX], o[kNX];
+    for (int k = 0; k < kNX; ++k) { a[k] = x0[(long)i * kNX + k]; b[k] = x1[(long)i * kNX + k]; }
+    for (int k = 0; k < kNDX; ++k) d[k] = dx[(long)i * kNDX + k];
+    double r[kNDX];
+    state_diff_q(a, b, r);
+    for (int k = 0; k < kNDX; ++k) dq[(long)i * kNDX + k] = r[k];
+    state_diff<false>(a, b, r, nullptr);
+    for (int k = 0; k < kNDX; ++k) dr[(long)i * kNDX + k] = r[k];
+    state_integrate_q(a, d, o);
+    for (int k = 0; k < kNX; ++k) iq[(long)i * kNX + k] = o[k];
+    state_integrate(a, d, o);
+    for (int k = 0; k < kNX; ++k) ir[(long)i * kNX + k] = o[k];
+}
+
 // the active-problem counter, copied to a host-mapped word: the host reads it after its stream synchronisation
 // without a device-to-host copy operation (a 4-byte hipMemcpy into pageable memory costs ~50 us per DDP iteration)
 __global__ void ik_publish_active_kernel(const int *active, volatile int *host_word) {
@@ -1215,6 +1250,11 @@ __global__ void kd_fill_refs_kernel(double *tasks, const double *X, double m, in
 hipError_t ik_launch_fill_refs(double *tasks, const double *X, double m, int B, int H, int T, hipStream_t st) {
     const long n = (long)B * (T + 1);
     hipLaunchKernelGGL(kd_fill_refs_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, tasks, X, m, B, H, T);
+    return hipGetLastError();
+}
+hipError_t ik_launch_state_ops_selftest(const double *x0, const double *x1, const double *dx, int n, double *dq, double *dr, double *iq, double *ir,
+                                        hipStream_t st) {
+    hipLaunchKernelGGL(ik_state_ops_selftest_kernel, dim3((n + 63) / 64), dim3(64), 0, st, x0, x1, dx, n, dq, dr, iq, ir);
     return hipGetLastError();
 }
 hipError_t ik_launch_publish_active(const int *active, int *host_word_dev, hipStream_t st) {

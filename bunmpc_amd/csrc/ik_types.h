@@ -110,6 +110,8 @@ hipError_t ik_launch_centroidal_state(const RobotModelDev *model, const double *
 // com (3) and h_g (6) along a state trajectory [B][n][37]  (InverseKinematics::return_opt_com/mom)
 hipError_t ik_launch_com_mom(const RobotModelDev *model, const double *xs, double *com, double *mom, int n_states, hipStream_t s);
 
+hipError_t ik_launch_state_ops_selftest(const double *x0, const double *x1, const double *dx, int n, double *dq, double *dr, double *iq, double *ir,
+                                        hipStream_t s);
 hipError_t ik_launch_fill_refs(double *tasks, const double *X, double m, int B, int H, int T, hipStream_t s);
 
 }  // namespace bunmpc

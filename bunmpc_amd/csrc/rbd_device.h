@@ -9,6 +9,7 @@ namespace bunmpc {
 namespace rbd {
 
 #define RBD_D __device__ __forceinline__
+#define UNROLL_RBD_DEV _Pragma("unroll")
 
 RBD_D void cross3(const double *a, const double *b, double *c) {
     const double c0 = a[1] * b[2] - a[2] * b[1], c1 = a[2] * b[0] - a[0] * b[2], c2 = a[0] * b[1] - a[1] * b[0];
@@ -232,6 +233,119 @@ RBD_D void state_diff(const double *x0, const double *x1, double *d, double *Jl)
     _Pragma("unroll") for (int i = 0; i < kNV - 6; ++i) d[6 + i] = x1[7 + i] - x0[7 + i];
     _Pragma("unroll") for (int i = 0; i < kNV; ++i) d[kNV + i] = x1[kNQ + i] - x0[kNQ + i];
     if (JAC) jlog6_of(d, Jl);
+}
+
+// ---- the same two state operators without rotation matrices, for the serial chains of the forward pass (x -> dx -> u -> x+):
+// quaternion algebra, reciprocals by v_rcp / v_rsq + Newton steps instead of the IEEE division / sqrt sequences (~25
+// dependent instructions each), one arctangent and no sine / cosine in the difference, one sincos of the half angle in the
+// step.  Same mathematics as state_diff<false> / state_integrate above (equal to a few ulp: tests/test_rbd_gpu.py), a third of
+// their instructions.
+RBD_D double rcp_fast(double b) {       // 1 / b to ~1 ulp
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    return fma(fma(-b, r, 1.0), r, r);
+}
+RBD_D double rsqrt_fast(double a) {     // 1 / sqrt(a) to ~1 ulp, a > 0 and far from the subnormals
+    double r = __builtin_amdgcn_rsq(a);
+    const double h = 0.5 * a;
+    r = fma(fma(-h * r, r, 0.5), r, r);
+    return fma(fma(-h * r, r, 0.5), r, r);
+}
+// atan(y / x) for x, y >= 0 (not both 0): in [0, pi/2].  fdlibm's atan polynomial on a reduced argument.
+RBD_D double atan2_pos(double y, double x) {
+    const bool swap = y > x;
+    const double num = swap ? x : y, den = swap ? y : x;      // t = num / den in [0, 1]
+    double t = num * rcp_fast(den);
+    // reduce [0, 1] to |t| <= tan(pi/8): atan(t) = pi/4 + atan((t - 1)/(t + 1)) for t > tan(pi/8)
+    const bool hi = t > 0.4142135623730950488;
+    const double tr = hi ? (t - 1.0) * rcp_fast(t + 1.0) : t;
+    const double z = tr * tr, w = z * z;
+    const double s1 = z * (3.33333333333329318027e-01 + w * (1.42857142725034663711e-01 + w * (9.09088713343650656196e-02 +
+                      w * (6.66107313738753120669e-02 + w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
+    const double s2 = w * (-1.99999999998764832476e-01 + w * (-1.11111104054623557880e-01 + w * (-7.69187620504482999495e-02 +
+                      w * (-5.83357013379057348645e-02 + w * -3.65315727442169155270e-02))));
+    double a = tr - tr * (s1 + s2);
+    a = hi ? 7.85398163397448278999e-01 + a : a;
+    return swap ? 1.57079632679489655800e+00 - a : a;
+}
+// rotate d by the unit quaternion (v, w): R d = d + 2 w (v x d) + 2 v x (v x d); transposed: the same with -v
+RBD_D void quat_rotate(const double *v, double w, const double *d, double *o) {
+    double t[3], u[3];
+    cross3(v, d, t);
+    UNROLL_RBD_DEV for (int i = 0; i < 3; ++i) t[i] *= 2.0;
+    cross3(v, t, u);
+    UNROLL_RBD_DEV for (int i = 0; i < 3; ++i) o[i] = d[i] + w * t[i] + u[i];
+}
+RBD_D void state_diff_q(const double *x0, const double *x1, double *d) {
+    // relative placement M0^-1 M1 as a unit quaternion and a translation in frame 0
+    const double n0 = rsqrt_fast(x0[3] * x0[3] + x0[4] * x0[4] + x0[5] * x0[5] + x0[6] * x0[6]);
+    const double n1 = rsqrt_fast(x1[3] * x1[3] + x1[4] * x1[4] + x1[5] * x1[5] + x1[6] * x1[6]);
+    const double a[3] = {x0[3] * n0, x0[4] * n0, x0[5] * n0}, aw = x0[6] * n0;
+    const double b[3] = {x1[3] * n1, x1[4] * n1, x1[5] * n1}, bw = x1[6] * n1;
+    double axb[3];
+    cross3(a, b, axb);
+    double qw = aw * bw + dot3(a, b);
+    double qv[3];
+    UNROLL_RBD_DEV for (int i = 0; i < 3; ++i) qv[i] = aw * b[i] - bw * a[i] - axb[i];
+    if (qw < 0.0) { qw = -qw; UNROLL_RBD_DEV for (int i = 0; i < 3; ++i) qv[i] = -qv[i]; }      // the rotation by at most pi
+    const double n2 = dot3(qv, qv);
+    double w[3], beta;
+    if (n2 < 1e-16) {      // theta = 2 asin(n) ~ 2 n: w = 2 v; beta -> 1/12
+        UNROLL_RBD_DEV for (int i = 0; i < 3; ++i) w[i] = 2.0 * qv[i];
+        beta = 1.0 / 12.0;
+    } else {
+        const double in = rsqrt_fast(n2), n = n2 * in;
+        const double th = 2.0 * atan2_pos(n, qw), ith = rcp_fast(th);
+        const double f = th * in;
+        UNROLL_RBD_DEV for (int i = 0; i < 3; ++i) w[i] = f * qv[i];
+        // beta = 1/theta^2 - cot(theta/2)/(2 theta), cot(theta/2) = qw / n; series where the two terms cancel
+        beta = th * th < 1e-6 ? 1.0 / 12.0 + th * th / 720.0 : ith * ith - 0.5 * (qw * in) * ith;
+    }
+    const double na[3] = {-a[0], -a[1], -a[2]};
+    const double dp[3] = {x1[0] - x0[0], x1[1] - x0[1], x1[2] - x0[2]};
+    double pr[3], wp[3], wwp[3];
+    quat_rotate(na, aw, dp, pr);              // R0^T (p1 - p0)
+    cross3(w, pr, wp);
+    cross3(w, wp, wwp);
+    UNROLL_RBD_DEV for (int i = 0; i < 3; ++i) { d[i] = pr[i] - 0.5 * wp[i] + beta * wwp[i]; d[3 + i] = w[i]; }
+    UNROLL_RBD_DEV for (int i = 0; i < kNV - 6; ++i) d[6 + i] = x1[7 + i] - x0[7 + i];
+    UNROLL_RBD_DEV for (int i = 0; i < kNV; ++i) d[kNV + i] = x1[kNQ + i] - x0[kNQ + i];
+}
+RBD_D void state_integrate_q(const double *x, const double *dx, double *xn) {
+    const double *v = dx, *w = dx + 3;
+    const double t2 = dot3(w, w);
+    double sh_t, ch, bb, cc;          // sin(theta/2)/theta, cos(theta/2), (1 - cos theta)/theta^2, (theta - sin theta)/theta^3
+    if (t2 < 1e-6) {
+        sh_t = 0.5 - t2 / 48.0 + t2 * t2 / 3840.0; ch = 1.0 - t2 / 8.0 + t2 * t2 / 384.0;
+        bb = 0.5 - t2 / 24.0 + t2 * t2 / 720.0; cc = 1.0 / 6.0 - t2 / 120.0 + t2 * t2 / 5040.0;
+    } else {
+        const double it = rsqrt_fast(t2), th = t2 * it;
+        double sh;
+        sincos_fast(0.5 * th, sh, ch);
+        sh_t = sh * it;
+        bb = 2.0 * sh_t * sh_t;                              // 2 sin^2(theta/2) / theta^2
+        cc = (th - 2.0 * sh * ch) * it * it * it;            // (theta - sin theta) / theta^3
+    }
+    const double nq = rsqrt_fast(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] + x[6] * x[6]);
+    const double q[3] = {x[3] * nq, x[4] * nq, x[5] * nq}, qw = x[6] * nq;
+    // p+ = p + R(q) (v + b w x v + c w x (w x v))
+    double wv[3], wwv[3], u[3], ru[3];
+    cross3(w, v, wv);
+    cross3(w, wv, wwv);
+    UNROLL_RBD_DEV for (int i = 0; i < 3; ++i) u[i] = v[i] + bb * wv[i] + cc * wwv[i];
+    quat_rotate(q, qw, u, ru);
+    UNROLL_RBD_DEV for (int i = 0; i < 3; ++i) xn[i] = x[i] + ru[i];
+    // q+ = q (x) (sin(theta/2)/theta w, cos(theta/2)), normalised
+    const double dv[3] = {sh_t * w[0], sh_t * w[1], sh_t * w[2]};
+    double qxd[3];
+    cross3(q, dv, qxd);
+    double r[4];
+    UNROLL_RBD_DEV for (int i = 0; i < 3; ++i) r[i] = qw * dv[i] + ch * q[i] + qxd[i];
+    r[3] = qw * ch - dot3(q, dv);
+    const double nr = rsqrt_fast(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+    UNROLL_RBD_DEV for (int i = 0; i < 4; ++i) xn[3 + i] = r[i] * nr;
+    UNROLL_RBD_DEV for (int i = 0; i < kNV - 6; ++i) xn[7 + i] = x[7 + i] + dx[6 + i];
+    UNROLL_RBD_DEV for (int i = 0; i < kNV; ++i) xn[kNQ + i] = x[kNQ + i] + dx[kNV + i];
 }
 
 // composite inertia about the world origin: mass, first moment h1 = m c, I_O (xx xy xz yy yz zz)

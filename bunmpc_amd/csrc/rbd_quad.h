@@ -110,8 +110,14 @@ RBD_D void body_momentum_r(const BodyRec &br, const double *R, const double *p, 
     Iw[2] = I[2] * wl[0] + I[4] * wl[1] + I[5] * wl[2];
     mat3vec(R, Iw, n);
     cross3(cw, l, t);
-    mass += mb;
-    UNROLL_RBD for (int c = 0; c < 3; ++c) { h1[c] += mb * cw[c]; h[c] += l[c]; h[3 + c] += n[c] + t[c]; }
+    double mc[3], nt[3];
+    UNROLL_RBD for (int c = 0; c < 3; ++c) { mc[c] = mb * cw[c]; nt[c] = n[c] + t[c]; }
+    {   // the body's terms join the running sums by plain additions: fused into the products above they would round differently
+        // from the sixteen-lane walk (quad_part16), which adds the same terms across lanes
+#pragma clang fp contract(off)
+        mass += mb;
+        UNROLL_RBD for (int c = 0; c < 3; ++c) { h1[c] += mc[c]; h[c] += l[c]; h[3 + c] += nt[c]; }
+    }
 }
 
 template <bool VEL>
@@ -268,6 +274,119 @@ RBD_D void quad_part(const RobotModelDev &m, const double *x, const double *qj, 
         UNROLL_RBD for (int c = 0; c < 9; ++c) Rp[c] = R[c];
         UNROLL_RBD for (int c = 0; c < 3; ++c) pp[c] = p[c];
         UNROLL_RBD for (int c = 0; c < 6; ++c) Vp[c] = V[c];
+    }
+}
+
+// ---- the same part sums with SIXTEEN lanes of a sub-group: lane l = 4 leg + j, j < 3 the joints of the leg, lane 3 the base
+// body (the spare lanes of the other quads idle).  quad_part walks a leg joint after joint on one lane; where the walk has a
+// wave of its own beside the rollout chain (the few-problems mappings of the forward pass) that scalar chain sets the pace of
+// a node (~15.8K cycles against ~14.6K of the chain).  Here every lane prepares its own joint (sincos, local rotation, body
+// constants) at once; only the composition of the world placement runs down the leg, each step computed by all lanes and
+// handed on inside the quad by DPP (quad_perm broadcast); then every lane takes the momentum of its own body and the quad
+// butterfly adds the three bodies of a leg -- (b0 + b1) + b2, the order quad_part accumulates in, so the sums carry the same
+// bits.  ~11.2K cycles per node there; in the many-problems mapping (everything on one wave, issue bound) the extra
+// instructions of the cooperative version cost more than they save, and quad_part stays.
+template <int CTRL>
+RBD_D double quad_dpp(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+RBD_D double quad_sum(double v) {      // (v0 + v1) + (v2 + v3) on every lane of the quad
+    v += quad_dpp<0xB1>(v);            // quad_perm:[1,0,3,2]
+    v += quad_dpp<0x4E>(v);            // quad_perm:[2,3,0,1]
+    return v;
+}
+// xs: the state in LDS (joint values are read by run-time index); o of lane 4 leg (j = 0): the leg's sums; o of lane 3: the base body's
+RBD_D void quad_part16(const RobotModelDev &m, const double *xs, const int *fid, int l, PartSum &o) {
+    const int leg = l >> 2, jj = l & 3;
+    const bool is_joint = jj < kLegJoints, is_base = l == 3;
+    const int i = kLegJoints * leg + (is_joint ? jj : 0);
+    double Rb[9], pb[3], Vb[6];
+    {
+        double xv[40];
+        double2_t t[20];
+        lds_read_b128x20(lds_offset(xs), t);
+        UNROLL_RBD for (int k = 0; k < 20; ++k) { xv[2 * k] = t[k].x; xv[2 * k + 1] = t[k].y; }
+        quat_to_R(xv + 3, Rb);
+        pb[0] = xv[0]; pb[1] = xv[1]; pb[2] = xv[2];
+        const double *v = xv + kNQ;
+        double wl[3], vl[3], tt[3];
+        mat3vec(Rb, v + 3, wl); mat3vec(Rb, v, vl); cross3(pb, wl, tt);
+        UNROLL_RBD for (int c = 0; c < 3; ++c) { Vb[c] = vl[c] + tt[c]; Vb[3 + c] = wl[c]; }
+    }
+    const double qi = is_joint ? xs[7 + i] : 0.0, vi = is_joint ? xs[kNQ + 6 + i] : 0.0;
+    BodyRec br;
+    load_body(m, is_joint ? i + 1 : 0, br);
+    double Rl[9];
+    rodrigues(br.axis, qi, Rl);                      // the base lane (axis of body 0 = 0, q = 0) gets the identity
+    if (__any(is_joint && !m.R_identity[i])) {       // joint placements with a rotation: none on Solo12 / Go2
+        double t9[9];
+        UNROLL_RBD for (int c = 0; c < 9; ++c) t9[c] = Rl[c];
+        if (is_joint && !m.R_identity[i]) mat3mul(m.R[i], t9, Rl);
+    }
+    double cur[9], pp[3], Vp[6], R[9], p[3], V[6];
+    UNROLL_RBD for (int c = 0; c < 9; ++c) { cur[c] = Rb[c]; R[c] = Rb[c]; }
+    UNROLL_RBD for (int c = 0; c < 3; ++c) { pp[c] = pb[c]; p[c] = pb[c]; }
+    UNROLL_RBD for (int c = 0; c < 6; ++c) { Vp[c] = Vb[c]; V[c] = Vb[c]; }
+    UNROLL_RBD for (int k = 0; k < kLegJoints; ++k) {
+        double cR[9], cp[3], S[6], t3[3];
+        mat3mul(cur, Rl, cR);
+        mat3vec(cur, br.p, t3);
+        UNROLL_RBD for (int c = 0; c < 3; ++c) cp[c] = t3[c] + pp[c];
+        mat3vec(cR, br.axis, S + 3);
+        cross3(cp, S + 3, S);
+        const bool mine = jj == k;
+        UNROLL_RBD for (int c = 0; c < 9; ++c) R[c] = mine ? cR[c] : R[c];
+        UNROLL_RBD for (int c = 0; c < 3; ++c) p[c] = mine ? cp[c] : p[c];
+        UNROLL_RBD for (int c = 0; c < 6; ++c) V[c] = mine ? Vp[c] + S[c] * vi : V[c];
+        if (k == 0) {
+            UNROLL_RBD for (int c = 0; c < 9; ++c) cur[c] = quad_dpp<0x00>(R[c]);
+            UNROLL_RBD for (int c = 0; c < 3; ++c) pp[c] = quad_dpp<0x00>(p[c]);
+            UNROLL_RBD for (int c = 0; c < 6; ++c) Vp[c] = quad_dpp<0x00>(V[c]);
+        } else if (k == 1) {
+            UNROLL_RBD for (int c = 0; c < 9; ++c) cur[c] = quad_dpp<0x55>(R[c]);
+            UNROLL_RBD for (int c = 0; c < 3; ++c) pp[c] = quad_dpp<0x55>(p[c]);
+            UNROLL_RBD for (int c = 0; c < 6; ++c) Vp[c] = quad_dpp<0x55>(V[c]);
+        }
+    }
+    double mass = 0.0, h1[3] = {0, 0, 0}, hO[6] = {0, 0, 0, 0, 0, 0};
+    body_momentum_r(br, R, p, V, mass, h1, hO);
+    const int my_body = is_joint ? i + 1 : (is_base ? 0 : -1);
+    double fx[kFrameSlots][3];
+    int hit[kFrameSlots];
+    UNROLL_RBD for (int s = 0; s < kFrameSlots; ++s) {
+        const int fb = fid[s] >= 0 ? m.frame_body[fid[s]] : -2;
+        hit[s] = fb == my_body;
+        double t3[3] = {0, 0, 0};
+        if (__any(hit[s])) {
+            const double *fp = m.frame_p[fid[s] >= 0 ? fid[s] : 0];
+            mat3vec(R, fp, t3);
+        }
+        UNROLL_RBD for (int c = 0; c < 3; ++c) fx[s][c] = hit[s] ? t3[c] + p[c] : 0.0;
+    }
+    if (is_base) {       // the base body's own terms, before the leg sums mix the quad
+        o.mass = mass;
+        UNROLL_RBD for (int c = 0; c < 3; ++c) o.h1[c] = h1[c];
+        UNROLL_RBD for (int c = 0; c < 6; ++c) o.hO[c] = hO[c];
+        UNROLL_RBD for (int s = 0; s < kFrameSlots; ++s) { o.fhit[s] = hit[s]; UNROLL_RBD for (int c = 0; c < 3; ++c) o.fx[s][c] = fx[s][c]; }
+    }
+    const double keep = is_joint ? 1.0 : 0.0;
+    const double ms = quad_sum(keep * mass);
+    double h1s[3], hOs[6];
+    UNROLL_RBD for (int c = 0; c < 3; ++c) h1s[c] = quad_sum(keep * h1[c]);
+    UNROLL_RBD for (int c = 0; c < 6; ++c) hOs[c] = quad_sum(keep * hO[c]);
+    if (!is_base) {
+        o.mass = ms;
+        UNROLL_RBD for (int c = 0; c < 3; ++c) o.h1[c] = h1s[c];
+        UNROLL_RBD for (int c = 0; c < 6; ++c) o.hO[c] = hOs[c];
+    }
+    UNROLL_RBD for (int s = 0; s < kFrameSlots; ++s) {
+        const double hs = quad_sum(is_joint && hit[s] ? 1.0 : 0.0);
+        double f3[3];
+        UNROLL_RBD for (int c = 0; c < 3; ++c) f3[c] = quad_sum(is_joint ? fx[s][c] : 0.0);
+        if (!is_base) { o.fhit[s] = hs != 0.0; UNROLL_RBD for (int c = 0; c < 3; ++c) o.fx[s][c] = f3[c]; }
     }
 }
 

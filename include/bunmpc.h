@@ -240,6 +240,9 @@ int bmpc_ik_solve_batch_device(const bmpc_ik_batch_t *d, void *hip_stream);
 /* Measurement aid (additive): with profiling on, the DDP loop brackets each of its kernels with events; after a batch solve
  * bmpc_ik_last_profile returns the summed milliseconds of ik_state / ik_calcdiff / ik_backward / ik_forward and of the rest
  * of the loop (bench.py's per-kernel split; rocprofv3 --kernel-trace gives the same numbers, profiles/). */
+/* self test (host arrays): the state operators diff(x0, x1) and x0 (+) dx of n samples, x [n][37], dx [n][36], by the
+ * quaternion versions the forward pass uses (dq [n][36], iq [n][37]) and by the rotation-matrix versions (dr, ir) */
+int bmpc_ik_selftest_state_ops(const double *x0, const double *x1, const double *dx, int n, double *dq, double *dr, double *iq, double *ir);
 int bmpc_ik_set_profile(int on);            /* returns the old setting */
 void bmpc_ik_last_profile(double *ms5);
 /* [com, vcom, hg.angular] of x = [q, v]: what KinoDynMP::optimize feeds the centroidal solve (kino_dyn.cpp:42,86-97) */

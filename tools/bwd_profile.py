@@ -10,13 +10,12 @@ for B in (1, 4096):
     wb = problems.make_wb_batch(model, B)
     kb = KinoDynDeviceBatch(wb, model, num_iters=10)
     kb.solve(); r = kb.results()
-    T = wb.ik_T    # IkLayout::make (csrc/ik_types.h) up to the Quuk slot
-    o = sum([(T + 1) * 37, T * 18, 4 * (T + 1) * 37, 4 * T * 18, (T + 1) * 36, T * 37, (T + 1) * 36, (T + 1) * 1296, T * 18, T * 18,
-             T * 36, T * 36, T * 648, T * 18, T * 18])
+    T = wb.ik_T
+    oq = kb.off["k"] + T * 18      # the Qu slot (unused by the solver: the stamped build parks its cycle counts there)
+    o = oq + T * 18                # the Quuk slot
     ws = kb.ws.cpu().numpy()
     c = ws[:, o:o + 9] / wb.ik_T      # last backward pass only
     names = "stage apply1 row+apply2 qxu+Lxx chol solve store+vx schur sym+fs".split()
-    oq = o - T * 18
     cd = ws[:, oq:oq + 4].mean(0)
     fw = ws[:, oq + 8:oq + 14].mean(0)
     print("B", B, "forward (last call) cycles to the node barrier / incl. barrier, summed over nodes and rounds: chain %d / %d, legs %d / %d, reg %d / %d" % tuple(fw))
