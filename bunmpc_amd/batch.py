@@ -66,8 +66,8 @@ class DeviceBatch:
         self.X = torch.empty((B, 9 * (H + 1)), dtype=f64, device=self.device)
         self.F = torch.empty((B, 3 * E * H), dtype=f64, device=self.device)
         self.P = torch.empty((B, 9 * (H + 1)), dtype=f64, device=self.device)
-        self.L_x = torch.empty(B, dtype=f64, device=self.device)
-        self.L_f = torch.empty(B, dtype=f64, device=self.device)
+        self.L_x = torch.full((B,), L0_X, dtype=f64, device=self.device)
+        self.L_f = torch.full((B,), L0_F, dtype=f64, device=self.device)
         self.dyn_viol = torch.zeros(B, dtype=f64, device=self.device)
         self.stats = torch.zeros((B, NSTATS), dtype=torch.int32, device=self.device)
         self.hist = torch.full((B, max(num_iters, 1)), float("nan"), dtype=f64,
@@ -98,9 +98,18 @@ class DeviceBatch:
         self.L_f.fill_(L0_F) if L_f is None else self.L_f.copy_(torch.as_tensor(np.asarray(L_f)))
         self.desc.cold_start = 0
 
-    def cold_start(self):
-        """Every solve starts as KinoDynMP::set_warm_starts does (kino_dyn.cpp:83-99)."""
-        self.desc.cold_start = 1
+    def cold_start(self, carry_step_constants=False):
+        """Every solve starts as KinoDynMP::set_warm_starts does (kino_dyn.cpp:83-99): X = tile(x_init), F = 0, P = 0.
+        carry_step_constants=False: with the constructor's FISTA constants too (a fresh KinoDynMP per problem: independent batch
+        elements).  True: L_x / L_f stay what the previous solve left (or set_step_constants set) -- the reference never resets
+        FISTA's L_ between the optimize calls of one object (fista.hpp:52), so this is the mode for successive replans of the same
+        rollouts."""
+        self.desc.cold_start = 2 if carry_step_constants else 1
+
+    def set_step_constants(self, L_x, L_f):
+        torch = self.torch
+        self.L_x.copy_(torch.as_tensor(np.broadcast_to(np.asarray(L_x, dtype=np.float64), self.L_x.shape).copy()))
+        self.L_f.copy_(torch.as_tensor(np.broadcast_to(np.asarray(L_f, dtype=np.float64), self.L_f.shape).copy()))
 
     def solve(self):
         """Asynchronous: one launch on torch's current stream."""

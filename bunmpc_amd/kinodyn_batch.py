@@ -56,6 +56,11 @@ class KinoDynDeviceBatch:
         d.x = self.x.data_ptr()
         self.desc = d
 
+    def carry_step_constants(self, on=True):
+        """True: the next solves are further optimize calls of the SAME KinoDynMP objects (successive replans of the same
+        rollouts): iterates reset, FISTA's step constants carried (bmpc_batch_t.cold_start = 2); False: fresh objects"""
+        self.desc.dyn.cold_start = 2 if on else 1
+
     def solve(self):
         """one full batch of KinoDynMP.optimize; synchronises once per DDP iteration (active counter)"""
         stream = self.torch.cuda.current_stream(self.device).cuda_stream

@@ -34,8 +34,11 @@ class BatchedMpc:
         self.offsets_xy = offs[:, :2]
         self._kb = self._plan = None
 
-    def optimize(self, x, t0, v_des_body):
-        """x (B,37), t0 (B,), v_des_body (B,3) numpy arrays or device tensors -> dict of device tensors: xs_int (B,R,37), us_int (B,R,18),
+    def optimize(self, x, t0, v_des_body, same_rollouts=False):
+        """same_rollouts=True: this call replans the rollouts of the previous call with the same batch size (the reference keeps
+        one KinoDynMP per rollout, whose FISTA step constants persist from replan to replan: fista.hpp:52); False: B fresh
+        rollouts (the data-generation passes).
+        x (B,37), t0 (B,), v_des_body (B,3) numpy arrays or device tensors -> dict of device tensors: xs_int (B,R,37), us_int (B,R,18),
         f_int (B,R,12), rows (B,) valid rows of each, plus the raw solution (xs, us, X, F).  The raw solution and `plan` are
         views of buffers the next call with the same batch size reuses: copy what has to outlive it."""
         import torch
@@ -46,6 +49,7 @@ class BatchedMpc:
             # same batch size as the last call: the plan tensors, the solver's workspace and its descriptors are reused
             plan, kb = self._plan, self._kb
             plan.update(x, t0, v_des_body).build()
+            kb.carry_step_constants(same_rollouts)
         else:
             plan = DeviceWbPlan(self.dm, self.gait, self.offsets_xy, self.wb.feet, self.ik, x, t0, v_des_body, self.H, self.T,
                                 device=self.device).build()

@@ -377,3 +377,34 @@ def test_both_mappings_at_full_size(oracle, mapping):
     e = np.maximum(rel_l2(out["wave"]["X"], out["batch"]["X"]), rel_l2(out["wave"]["F"], out["batch"]["F"]))
     print("wave vs batch mapping over 4096 problems: median %.2e, max %.2e, above 1e-9: %d" % (np.median(e), e.max(), (e > 1e-9).sum()))
     assert np.median(e) < 1e-13 and (e > 1e-9).mean() < 0.02 and e.max() < 1e-3      # a few problems sit in the chaotic regime (tests/util.py)
+
+
+def test_cold_start_that_carries_the_step_constants(oracle, mapping):
+    """bmpc_batch_t.cold_start = 2: the next optimize call of the same KinoDynMP objects -- iterates reset by set_warm_starts
+    (kino_dyn.cpp:83-99), FISTA's L_ carried from the call before (fista.hpp:52: it is set in the constructor only)."""
+    b = problems.make_batch("solo12_trot", 5)
+    pre = oracle.solve_batch(b, num_iters=0)
+    X0, F0, P0 = b.warm_start()
+    for which in ("batch", "wave"):
+        mapping(which)
+        dev = bb.DeviceBatch(b, num_iters=3)
+        dev.cold_start(carry_step_constants=True)
+        dev.set_step_constants(2e5, 40.0)            # low enough to force retries, which must persist into the second call
+        Lx, Lf = np.full(5, 2e5), np.full(5, 40.0)
+        for call in range(2):
+            dev.solve()
+            got = dev.results()
+            for i in range(b.B):
+                r = oracle.biconvex_solve(b.cnt_plan[i], b.dt[i], b.m, b.x_init[i], pre["Qx"][i], pre["qx"][i], pre["Qf"][i], pre["lbx"][i],
+                                          pre["ubx"][i], X0[i], F0[i], P0[i], L_x=Lx[i], L_f=Lf[i], rho=b.rho, num_iters=3)
+                assert np.array_equal(got["stats"][i], r["stats"]), (which, call, i)
+                assert got["L_x"][i] == r["L_x"] and got["L_f"][i] == r["L_f"]
+                assert rel_l2(got["X"][i], r["X"]) < TOL and rel_l2(got["F"][i], r["F"]) < TOL
+                Lx[i], Lf[i] = r["L_x"], r["L_f"]
+            if call == 0:
+                assert got["stats"][:, 3:5].sum() > 0 and np.all(got["L_x"] > 2e5)
+            else:
+                assert got["stats"][:, 3:5].sum() == 0           # the constants found in the first call hold in the second
+        dev.cold_start()                                         # a fresh object again: the constructor's constants
+        dev.solve()
+        assert np.all(dev.results()["L_x"] == 2.25e6)
