@@ -519,6 +519,13 @@ __device__ __forceinline__ void lds_read_mfma_acc_upper(unsigned base, double (&
 __device__ __forceinline__ double lane_value(double v, int src) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
 }
+// 1 / sqrt(a) to ~1 ulp: v_rsq_f64 + two Newton steps (a > 0; NaN for a < 0, which the caller has flagged by then)
+__device__ __forceinline__ double rsqrt64(double a) {
+    double r = __builtin_amdgcn_rsq(a);
+    const double h = 0.5 * a;
+    r = fma(fma(-h * r, r, 0.5), r, r);
+    return fma(fma(-h * r, r, 0.5), r, r);
+}
 // 1 / b to ~1 ulp: v_rcp_f64 + two Newton steps
 __device__ __forceinline__ double rcp64(double b) {
     double r = __builtin_amdgcn_rcp(b);
@@ -529,8 +536,8 @@ __device__ __forceinline__ double rcp64(double b) {
 struct alignas(16) BackwardLds {
     double N[kPadRows * LD + 16];   // row-major staging: N = F_x^T V for the transposition, later Q_xx -> V_xx rows
     double Ys[kPadRows * LDK];      // Y^T, Y = L^-1 Q_ux (36 x 18 in a zeroed 48 x 21 image): both operands of the Schur update
-    double Lc[5 * 36];              // Cholesky factor packed by columns (L[q][p], q > p, at p(35-p)/2 + q-p-1), read back by
-                                    // broadcast in batches of 36
+    double Lc[5 * 36];              // Cholesky factor packed by rows (L[p][q], q < p, at p(p-1)/2 + q), read back by broadcast in
+                                    // batches of 36
     double A6[36], B6[36];
     double Vx[kNDX], fs[kNDX];
 };
@@ -555,6 +562,15 @@ __device__ __forceinline__ void apply_FxT(double (&x)[kNDX], unsigned a6_addr, u
     UNROLL_RBD for (int k = 6; k < kNV; ++k) x[kNV + k] = dt * x[k] + x[kNV + k];
 }
 
+// The workgroup of the backward pass is ONE wave: its LDS accesses execute in program order, so what a barrier has to provide
+// is only that the compiler keeps them in that order and that earlier LDS operations have completed.  __syncthreads() would
+// also wait for every outstanding GLOBAL load (s_waitcnt vmcnt(0)) -- here that is the prefetched L_xx row of the node, which
+// is not needed before the elimination and should keep flying across the exchanges in between.
+__device__ __forceinline__ void wave_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
     __shared__ BackwardLds s;
     const long b = slot_problem(a, blockIdx.x);
@@ -573,7 +589,7 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
     if (sc[S_RECALC] != 0.0) {
         // SolverDDP::calcDiff tail: total cost and the gaps fs
         if (lane == 0) { double c = 0.0; for (int t = 0; t <= T; ++t) c += ws[L.fs + (long)t * kNDX]; sc[S_COST] = c; }
-        __syncthreads();
+        wave_sync();
         if (!feas) {
             double mx = 0.0;
             if (lane <= T) {
@@ -590,7 +606,7 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
         } else {
             if (lane <= T) ws[L.fs + (long)lane * kNDX] = 0.0;   // the parked node costs
         }
-        __syncthreads();
+        wave_sync();
     }
 
     const bool row = lane < kNDX;                  // owns row `lane` of the 36x36 matrices
@@ -617,12 +633,12 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
         double vx = row ? ws[L.Lx + (long)T * kNDX + r] : 0.0;
         if (!feas) {
             if (row) s.fs[r] = ws[L.fs + (long)T * kNDX + r];
-            __syncthreads();
+            wave_sync();
             double acc = 0.0, fsv[kNDX];
             lds_read_row36(fs_addr, fsv);
             UNROLL_RBD for (int j = 0; j < kNDX; ++j) acc += m[j] * fsv[j];
             vx += acc;
-            __syncthreads();
+            wave_sync();
         }
 
         for (int t = T - 1; t >= 0; --t) {
@@ -642,11 +658,11 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             }
             if (lane < 36) { s.A6[lane] = ws[L.A6 + (long)t * 36 + lane]; s.B6[lane] = ws[L.B6 + (long)t * 36 + lane]; }
             if (row) { s.Vx[r] = vx; s.fs[r] = ws[L.fs + (long)t * kNDX + r]; }
-            __syncthreads();
+            wave_sync();
             PSTAMPV(0, m[0])
             apply_FxT(m, a6_addr, b6_addr, dt);                  // column r of N = F_x^T V
             if (row) { UNROLL_RBD for (int i = 0; i < kNDX; ++i) s.N[i * LD + r] = m[i]; }
-            __syncthreads();
+            wave_sync();
             PSTAMPV(1, m[0])
             lds_read_row36(row_addr, m);                         // row r of N
             apply_FxT(m, a6_addr, b6_addr, dt);                  // row r of G = N F_x
@@ -677,22 +693,37 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             PSTAMPV(3, al[17])
             // Pivots and the column entries every lane needs travel by v_readlane (wave-uniform, no LDS, no waiting).  A
             // non-positive or NaN pivot fails the pass (Eigen::LLT info != Success).
+            // One reciprocal square root per pivot serves both uses (1 / piv = rs^2 for the elimination, rs for the scaling of the
+            // column), and the NEXT pivot's is started as soon as its entry has had this pivot's update -- before the rest of
+            // the trailing update, whose independent instructions then fill the waits of that dependent chain.
             double idg[kNV];
-            UNROLL_RBD for (int j = 0; j < kNV; ++j) {
-                const double piv = lane_value(al[j], kNDX + j) + lane_value(dgv, kNDX + j);
+            double rs;
+            {
+                const double piv = lane_value(al[0], kNDX) + lane_value(dgv, kNDX);
                 if (!(piv > 0.0)) bad = true;
-                const double f = al[j] * rcp64(piv);
-                UNROLL_RBD for (int q = j + 1; q < kNV; ++q) al[q] -= f * lane_value(al[j], kNDX + q);
-                idg[j] = rcp64(sqrt(piv));
-                al[j] *= idg[j];                        // L[p][j] (rows p > j) / Y^T[r][j] / y_u[j]
+                rs = rsqrt64(piv);
+            }
+            UNROLL_RBD for (int j = 0; j < kNV; ++j) {
+                idg[j] = rs;
+                const double f = al[j] * (rs * rs);
+                double rs_next = 0.0;
+                if (j + 1 < kNV) {
+                    al[j + 1] -= f * lane_value(al[j], kNDX + j + 1);
+                    const double piv = lane_value(al[j + 1], kNDX + j + 1) + lane_value(dgv, kNDX + j + 1);
+                    if (!(piv > 0.0)) bad = true;
+                    rs_next = rsqrt64(piv);
+                }
+                UNROLL_RBD for (int q = j + 2; q < kNV; ++q) al[q] -= f * lane_value(al[j], kNDX + q);
+                al[j] *= rs;                            // L[p][j] (rows p > j) / Y^T[r][j] / y_u[j]
+                rs = rs_next;
             }
             PSTAMPV(4, idg[17])
             // The factor goes to LDS once (packed by columns): the back substitutions read it back by broadcast -- one
             // ds_read_b128 per two entries instead of four v_readlane.
-            if (urow) {
+            if (urow) {      // row p of L (its p entries left of the diagonal) is at hand on lane 36 + p: packed by rows
                 const int p = lane - kNDX;
                 UNROLL_RBD for (int q = 0; q < kNV - 1; ++q) {
-                    if (q < p) s.Lc[q * (35 - q) / 2 + (p - q - 1)] = al[q];
+                    if (q < p) s.Lc[p * (p - 1) / 2 + q] = al[q];
                 }
             }
             double (&y)[kNV] = al;
@@ -704,25 +735,25 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             // registers) and before the stores of K, V_x and the improvement terms, which the vector pipe does while the matrix
             // pipe works through its tiles.
             if (row) { UNROLL_RBD for (int p = 0; p < kNV; ++p) s.Ys[r * LDK + p] = y[p]; }
-            __syncthreads();
+            wave_sync();
             // V_xx = Q_xx - Y^T Y on the matrix pipe (layouts at BackwardLds): fp64 MFMA has the vector FMA rate on gfx950, so this
             // is not about flops -- one MFMA replaces 16 wave-wide FMAs in the issue stream, and every lane feeds ONE element of
             // Y per step instead of all lanes reading a whole 36 x 18 matrix by broadcast (51 ds_read_b64 per lane against 342
             // ds_read_b128 of the vector version).  The product is symmetric and V_xx is symmetrised right after: only the six
             // tiles on and above the block diagonal are computed (independent accumulators, k outermost); an off-diagonal tile is
             // stored a second time, transposed, where its mirror image belongs.
-            {
+            {   // back substitution L^T k = y, column by column: once k_p is final its multiples leave all earlier equations --
+                // independent updates (the row form accumulated each k_p through a chain of dependent FMAs)
                 const unsigned lc_addr = lds_offset(s.Lc);
                 double2_t lb[18];
                 int cur = -1;
                 UNROLL_RBD for (int p = kNV - 1; p >= 0; --p) {
-                    double w = y[p];
-                    UNROLL_RBD for (int q = kNV - 1; q > p; --q) {      // descending, so the batches are met from the last to the first
-                        const int idx = p * (35 - p) / 2 + (q - p - 1), bb = idx / 36, e = idx % 36;
+                    y[p] *= idg[p];
+                    UNROLL_RBD for (int q = p - 1; q >= 0; --q) {      // descending, so the batches are met from the last to the first
+                        const int idx = p * (p - 1) / 2 + q, bb = idx / 36, e = idx % 36;
                         if (bb != cur) { lds_read_b128x18(lc_addr + (unsigned)bb * 288, lb); cur = bb; }
-                        w -= ((e & 1) ? lb[e >> 1].y : lb[e >> 1].x) * y[q];
+                        y[q] -= ((e & 1) ? lb[e >> 1].y : lb[e >> 1].x) * y[p];
                     }
-                    y[p] = w * idg[p];
                 }
             }
             PSTAMPV(5, y[0])
@@ -761,23 +792,22 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
                         const int tl = (I == 0 ? 0 : I == 1 ? 2 : 3) + J;
                         UNROLL_RBD for (int v = 0; v < 4; ++v) {
                             const int i = 16 * I + lk + 4 * v, j = 16 * J + li;
-                            s.N[i * LD + j] = acc[tl][v];
+                            // V = (V_xx + V_xx^T)/2 + xreg I: xreg joins the staged diagonal here (a diagonal entry averages with itself)
+                            s.N[i * LD + j] = (J == I && i == j) ? acc[tl][v] + xreg : acc[tl][v];
                             if (J > I) s.N[j * LD + i] = acc[tl][v];
                         }
                     }
-            __syncthreads();
+            wave_sync();
             PSTAMPV(7, vx)
-            // V = (V_xx + V_xx^T)/2 + xreg I: own row and own column of the staged V_xx (xreg added to the staged diagonal)
-            if (row) s.N[r * LD + r] += xreg;
-            __syncthreads();
             lds_read_row36(row_addr, m);
             {
-                double col[kNDX];
+                double col[kNDX], chk = 0.0;
                 lds_read_col36_ld37(col_addr, col);
                 UNROLL_RBD for (int j = 0; j < kNDX; ++j) {
                     m[j] = 0.5 * (m[j] + col[j]);
-                    bad = bad || !(fabs(m[j]) < INFINITY);
+                    chk = fma(m[j], 0.0, chk);          // NaN as soon as one entry is NaN or infinite
                 }
+                bad = bad || !(chk == 0.0);
             }
             if (!feas) {
                 double acc = 0.0, fsv[kNDX];
@@ -787,7 +817,7 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             }
             bad = bad || !(fabs(vx) < INFINITY);       // raiseIfNaN on Vx / Vxx
             bad = __any(bad && (row || lane < kNV));
-            __syncthreads();
+            wave_sync();
             PSTAMPV(8, vx)
             if (bad) break;
         }
