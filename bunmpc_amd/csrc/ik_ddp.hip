@@ -883,6 +883,16 @@ struct ForwardLds { RobotModelDev m; FwdSub sub[kFwdSub]; double vote[kFwdSub], 
 // anyway), while wave 0 runs the chain x -> dx -> u -> Euler step -> next x; they meet once per node.  Different code
 // cannot overlap inside a wave, but it can across the waves of a workgroup.  Two waves while the problems still cover
 // the chip (<= 1024 active), three once a third of the SIMDs would be idle anyway.
+// Barrier of the forward pass' workgroup.  Its waves exchange through LDS only (the trial trajectories they write to the
+// workspace are read back after the kernel, or by the same wave), so the barrier needs the LDS operations complete, not the
+// global ones: __syncthreads() would also drain the rows of K and the task blocks that are fetched one node ahead, five times
+// per node.  One wave (the many-problems mapping): no s_barrier at all (wave_sync above).
+template <int NW>
+__device__ __forceinline__ void fwd_sync() {
+    if (NW == 1) wave_sync();
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a) {
     __shared__ ForwardLds s;
@@ -919,7 +929,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
         if (t < a.T || a.sn_ctrl_w == 0) { for (int i = l; i < kNV; i += kFwdLanes) q.cw[i] = gcw[a.sn_ctrl_w * t + i]; }
     };
     if (live && do_chain) stage_reg(0);
-    __syncthreads();
+    fwd_sync<NW>();
     const RobotModelDev &m = s.m;
     const double cost = sc[S_COST], d1 = sc[S_D1], d2 = sc[S_D2];
     const bool feas = sc[S_FEAS] != 0.0;
@@ -955,7 +965,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
             UNROLL_RBD for (int j = 0; j < kNDX; ++j) { kp0[j] = K0[j]; kp1[j] = K1[j]; }
             up0 = ws[L.us + l]; up1 = ws[L.us + l + 9]; fp0 = ws[L.kff + l]; fp1 = ws[L.kff + l + 9];
         }
-        __syncthreads();
+        fwd_sync<NW>();
         for (int t = 0; t <= T; ++t) {   // t == T: terminal node (cost only)
             if (!__any(run)) break;
 #ifdef BWD_PROFILE
@@ -1029,7 +1039,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
                     UNROLL_RBD for (int c = 0; c < 3; ++c) q.part[l][10 + 3 * f + c] = ps.fhit[f] ? ps.fx[f][c] : 0.0;
             }
             FSTAMP(1)
-            if (NW == 1) __syncthreads();   // with several waves each side hands over inside its own wave (LDS keeps a wave's order)
+            if (NW == 1) fwd_sync<NW>();   // with several waves each side hands over inside its own wave (LDS keeps a wave's order)
             // phase 3: feedback u = u - alpha k - K dx, two rows per lane (0..8 own rows l and l + 9), rows fetched a node ahead
             if (run && do_chain && !terminal && l < 9) {
                 double v0 = up0 - al * fp0, v1 = up1 - al * fp1, dxv[kNDX];
@@ -1045,7 +1055,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
                 }
             }
             FSTAMP(2)
-            if (NW == 1) __syncthreads();
+            if (NW == 1) fwd_sync<NW>();
             // phase 4: control cost + Euler step (lane 6)
             if (run && do_chain && l == 6) {
                 double acc = 0.0;
@@ -1064,7 +1074,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
                 q.bc[3] = tk.ctrl_w() * 0.5 * acc;
             }
             FSTAMP(3)
-            if (NW == 1) __syncthreads();
+            if (NW == 1) fwd_sync<NW>();
             // phase 5: the parts added up: CoM, centroidal momentum, their residual costs (without the state / control terms)
             if (run && do_cost && l == 0) {
                 double M = 0.0, h1[3] = {0, 0, 0}, hO[6] = {0, 0, 0, 0, 0, 0}, fx[kFrameSlots][3];
@@ -1108,7 +1118,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
 #ifdef BWD_PROFILE
             { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); fwork += __builtin_readcyclecounter() - fnode0; }
 #endif
-            __syncthreads();
+            fwd_sync<NW>();
 #ifdef BWD_PROFILE
             fwait += __builtin_readcyclecounter() - fnode0;
 #endif
@@ -1128,7 +1138,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
                 }
                 if (bad) run = false;       // tryStep threw: this step length is out
             }
-            __syncthreads();
+            fwd_sync<NW>();
             FSTAMP(4)
         }
         bool pass = false;               // the trial ran to the end and passes SolverDDP's acceptance test
@@ -1143,10 +1153,10 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
             // this workgroup's results to the workspace; the last of the problem's three workgroups to arrive decides
             if (l == 0 && ia < 10) { ws[L.votes + 2 * ia] = pass ? 1.0 : 0.0; ws[L.votes + 2 * ia + 1] = ctry; }
             __threadfence();
-            __syncthreads();
+            fwd_sync<NW>();
             unsigned *arrive = reinterpret_cast<unsigned *>(ws + L.arrive);
             if (threadIdx.x == 0) s.vote[0] = atomicAdd(arrive, 1u) == 2u ? 1.0 : 0.0;
-            __syncthreads();
+            fwd_sync<NW>();
             if (s.vote[0] == 0.0) return;
             __threadfence();
             if (threadIdx.x == 0) *arrive = 0u;
@@ -1160,14 +1170,14 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
             break;
         } else {
             if (l == 0) { s.vote[si] = pass ? 1.0 : 0.0; s.ctry[si] = ctry; }
-            __syncthreads();
+            fwd_sync<NW>();
             int w = -1;
             UNROLL_RBD for (int k = kFwdSub - 1; k >= 0; --k) if (s.vote[k] != 0.0) w = k;    // first in SolverDDP's order
             if (live) {
                 if (w >= 0) { accepted = true; win = w; alpha = ldexp(1.0, -(kFwdSub * round + w)); cost_try = s.ctry[w]; live = false; }
                 else if (kFwdSub * (round + 1) >= 10) { alpha = ldexp(1.0, -9); live = false; }   // every step length tried
             }
-            __syncthreads();
+            fwd_sync<NW>();
         }
     }
 #ifdef BWD_PROFILE
