@@ -84,7 +84,7 @@ __device__ __forceinline__ void euler_step(const double *x, const double *u, dou
     double dx[kNDX];
     const double *v = x + kNQ;
     UNROLL_RBD for (int i = 0; i < kNV; ++i) { dx[i] = v[i] * dt + u[i] * dt * dt; dx[kNV + i] = u[i] * dt; }
-    if (JAC) state_integrate(x, dx, xnext); else state_integrate_q(x, dx, xnext);
+    state_integrate_q(x, dx, xnext);
     if (JAC) {
         double dR[9], dp[3];
         exp6(dx, dR, dp);

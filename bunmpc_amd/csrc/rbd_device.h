@@ -221,8 +221,14 @@ RBD_D void state_integrate(const double *x, const double *dx, double *xn) {
     _Pragma("unroll") for (int i = 0; i < kNV; ++i) xn[kNQ + i] = x[kNQ + i] + dx[kNV + i];
 }
 // d = x1 (-) x0 (36); optionally the 6x6 Jlog6 of the base block (d diff / d x1)
+RBD_D void state_diff_q(const double *x0, const double *x1, double *d);
 template <bool JAC>
 RBD_D void state_diff(const double *x0, const double *x1, double *d, double *Jl) {
+    if (JAC) {      // the difference by the quaternion route (below), its Jacobian block from the difference
+        state_diff_q(x0, x1, d);
+        jlog6_of(d, Jl);
+        return;
+    }
     double R0[9], R1[9], Rr[9], dp[3], pr[3];
     quat_to_R(x0 + 3, R0); quat_to_R(x1 + 3, R1);
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
