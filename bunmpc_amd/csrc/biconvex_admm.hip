@@ -56,7 +56,7 @@ namespace {
 //   * a problem that finishes (|d| < tol or maxit) has its iterate latched into `fin` registers
 //     at that moment; the loop body itself carries no per-lane freeze selects.
 template <typename R, int LPP, int E, bool RAW, bool HASQF>
-__global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
+__device__ __forceinline__ void admm_body(const BatchArgs &a) {
     extern __shared__ double lds_raw[];
     R *cmtab = reinterpret_cast<R *>(lds_raw);   // [maxit]
     constexpr int NF = 3 * E;           // force variables per knot
@@ -495,6 +495,15 @@ __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) {
             s[0] = n_admm; s[1] = it_f; s[2] = it_x; s[3] = bt_f; s[4] = bt_x; s[5] = status;
         }
     }
+}
+
+// Two waves per SIMD (256 registers each).  The body wants 284-307 (fp32) / 314-370 (fp64) registers, so the cap moves the
+// coldest 40-90 values to scratch (150-370 B per lane, outside the FISTA loops); in exchange each wave's dependent-latency
+// stalls are filled by the other.  Measured at B = 4096 on MI355X: fp32 Go2 H=40 9.0 -> 7.1 ms, fp64 Solo12 H=20 4.33 -> 4.17 ms,
+// fp64 Go2 H=40 9.8 -> 9.56 ms (the fp64 loop is bound by the half-rate fp64 VALU, the fp32 one by latency).
+template <typename R, int LPP, int E, bool RAW, bool HASQF>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void biconvex_admm_kernel(const BatchArgs a) {
+    admm_body<R, LPP, E, RAW, HASQF>(a);
 }
 
 __global__ __launch_bounds__(64) void lane_selftest_kernel(const double *in, double *out) {
