@@ -176,6 +176,7 @@ _SIGS = {
     "bmpc_ik_set_profile": (_I, [_I]),
     "bmpc_ik_set_all_steps": (_I, [_I]),
     "bmpc_ik_batch_struct_size": (_I, []),
+    "bmpc_ik_active_list_ints": (C.c_long, [C.c_long]),
     "bmpc_ik_last_profile": (None, [_P]),
     "bmpc_ik_solve_batch_device": (_I, [_P, _P]),
     "bmpc_ik_centroidal_state_device": (_I, [_P, _P, _P, _I, _P]),

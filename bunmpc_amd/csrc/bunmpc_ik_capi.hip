@@ -148,7 +148,7 @@ bunmpc::IkBatchArgs make_args(int B, int T, int maxiter, const bmpc_model *model
     a.x0 = x0; a.dt = dt; a.tasks = tasks; a.state_w = state_w; a.x_reg = x_reg; a.ctrl_w = ctrl_w;
     a.s_state_w = s_sw; a.s_ctrl_w = s_cw; a.ws = ws; a.active = active;
     a.s_x_reg = bunmpc::kNX; a.sn_state_w = a.sn_x_reg = a.sn_ctrl_w = 0; a.fwd_spec = 0;
-    a.list = nullptr; a.count = nullptr; a.iter = 0; a.n_launch = B;
+    a.list = nullptr; a.count = nullptr; a.wide = nullptr; a.wcount = nullptr; a.iter = 0; a.n_launch = B;
     return a;
 }
 
@@ -643,7 +643,7 @@ int bmpc_ik_solve_batch_device(const bmpc_ik_batch_t *d, void *hip_stream) {
                               d->ctrl_w, d->s_ctrl_w, d->ws, d->active);
     a.s_x_reg = d->s_x_reg ? d->s_x_reg : kNX;
     a.sn_state_w = d->sn_state_w; a.sn_x_reg = d->sn_x_reg; a.sn_ctrl_w = d->sn_ctrl_w;
-    if (d->active_list) { a.list = d->active_list; a.count = d->active_list + 2 * (long)d->B; }
+    if (d->active_list) { a.list = d->active_list; a.count = a.list + 2 * (long)d->B; a.wcount = a.count + 2; a.wide = a.wcount + 2; }
     int iters = 0;
     int rc = run_ddp(a, static_cast<hipStream_t>(hip_stream), &iters);
     if (d->iters_run) *d->iters_run = iters;
@@ -661,6 +661,8 @@ void bmpc_ik_layout(int n_col, long *offsets8) {   // xs, us, scal, K, kff, fs, 
     offsets8[0] = L.xs; offsets8[1] = L.us; offsets8[2] = L.scal; offsets8[3] = L.K; offsets8[4] = L.kff;
     offsets8[5] = L.fs; offsets8[6] = L.Lx; offsets8[7] = L.Lxx;
 }
+
+long bmpc_ik_active_list_ints(long B) { return bunmpc::active_list_ints(B); }
 
 void bmpc_ik_layout_trace(int n_col, long *offset, int *iters, int *width) {   // the per-iteration telemetry rows of a problem's workspace
     const bunmpc::IkLayout L = bunmpc::IkLayout::make(n_col);

@@ -139,10 +139,10 @@ __global__ void ik_init_kernel(const IkBatchArgs a) {
     for (int i = 0; i < kNX; ++i) ws[L.xs_try + i] = a.x0[b * kNX + i];   // xs_try_[0] = x0
     double *s = ws + L.scal;
     s[S_COST] = 0; s[S_XREG] = 1e-9; s[S_D1] = 0; s[S_D2] = 0; s[S_STOP] = 0; s[S_FEAS] = 0; s[S_WASFEAS] = 0;
-    s[S_DONE] = 0; s[S_ITERS] = 0; s[S_RECALC] = 1; s[S_STATUS] = 0;
+    s[S_DONE] = 0; s[S_ITERS] = 0; s[S_RECALC] = 1; s[S_STATUS] = 0; s[S_WIDE] = 0; s[S_WIDENOW] = 0;
     ws[L.arrive] = 0.0;          // (read as an unsigned counter)
     if (a.list) a.list[b] = (int)b;
-    if (b == 0) { *a.active = a.B; if (a.count) { a.count[0] = a.B; a.count[1] = 0; } }
+    if (b == 0) { *a.active = a.B; if (a.count) { a.count[0] = a.B; a.count[1] = 0; a.wcount[0] = 0; a.wcount[1] = 0; } }
 }
 
 // --------------------------------------------------------------------------- calcDiff ---
@@ -222,7 +222,7 @@ __device__ __forceinline__ double node_state_terms(const IkBatchArgs &a, long b,
 __global__ __launch_bounds__(64) void ik_state_kernel(const IkBatchArgs a) {
     const int nn = a.T + 1;
     const long idx = (long)blockIdx.x * 64 + threadIdx.x;
-    if (idx == 0 && a.count) a.count[(a.iter + 1) & 1] = 0;     // the list this iteration's forward pass will fill
+    if (idx == 0 && a.count) { a.count[(a.iter + 1) & 1] = 0; a.wcount[(a.iter + 1) & 1] = 0; }     // the lists this iteration's forward pass will fill
     const long b = slot_problem(a, idx / nn);
     const int tw = (int)(idx % nn);
     if (b < 0) return;
@@ -902,14 +902,26 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
     // fwd_spec == 4: THREE workgroups per problem, workgroup g trying step lengths 2^-(4g + s): all ten in one round, on
     // separate CUs (inside one workgroup the register budget of seven waves did not allow it); the last of the
     // three to finish takes SolverDDP's decision for the problem
-    const bool all10 = NW == 3 && a.fwd_spec == 4;
-    const int grp = all10 ? (int)(blockIdx.x % 3) : 0;
-    const long b = slot_problem(a, all10 ? (long)(blockIdx.x / 3) : spec ? (long)blockIdx.x : (long)blockIdx.x * kFwdSub + si);
+    const bool all10_batch = NW == 3 && a.fwd_spec == 4;
+    // ... or for the flagged problems only (S_WIDENOW, set by the pass before): their two extra workgroups are the FIRST
+    // 2 kWideMax of the grid, two per place of the wide list (first, so that they start with the first wave of workgroups
+    // when the grid is larger than the chip; the unused ones return at once), the regular ones follow
+    const bool widegrid = NW > 1 && !all10_batch && a.wide != nullptr;
+    const long blk = (long)blockIdx.x - (widegrid ? 2 * kWideMax : 0);
+    const bool extra = widegrid && blk < 0;
+    int grp = all10_batch ? (int)(blockIdx.x % 3) : 0;
+    long b;
+    if (extra) {
+        const int e = (int)(blockIdx.x >> 1), cur = a.iter & 1, nw = a.wcount[cur] < kWideMax ? a.wcount[cur] : kWideMax;
+        b = e < nw ? (long)a.wide[cur * kWideMax + e] : -1;
+        grp = 1 + (int)(blockIdx.x & 1);
+    } else b = slot_problem(a, all10_batch ? blk / 3 : spec ? blk : blk * kFwdSub + si);
     const bool pvalid = b >= 0;
     const long bb = pvalid ? b : 0;
     const IkLayout L = IkLayout::make(a.T);
     double *ws = a.ws + bb * L.total;
     double *sc = ws + L.scal;
+    const bool all10 = all10_batch || (NW > 1 && spec && a.wide && pvalid && sc[S_WIDENOW] != 0.0);
     FwdSub &q = s.sub[si];
     bool live = pvalid && sc[S_DONE] == 0.0;     // this sub-group still has a line search to do
     if (!__any(live)) return;
@@ -936,7 +948,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
     const double *state_w = q.sw, *ctrl_w = q.cw, *x_reg = q.xreg;
     const double *gtasks = a.tasks + bb * nn * kNodeTaskDoubles, *gdt = a.dt + bb * T;
     const bool owner = live;            // sub-groups that take part at all
-    bool accepted = false;
+    bool accepted = false, widen = false;
     int win = 0;                        // trial slot holding the accepted trajectory
     double alpha = 1.0, cost_try = 0.0;
 #ifdef BWD_PROFILE
@@ -1173,6 +1185,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
             fwd_sync<NW>();
             int w = -1;
             UNROLL_RBD for (int k = kFwdSub - 1; k >= 0; --k) if (s.vote[k] != 0.0) w = k;    // first in SolverDDP's order
+            if (live && w < 0 && round == 0) widen = true;     // past the first four step lengths: flagged from now on
             if (live) {
                 if (w >= 0) { accepted = true; win = w; alpha = ldexp(1.0, -(kFwdSub * round + w)); cost_try = s.ctry[w]; live = false; }
                 else if (kFwdSub * (round + 1) >= 10) { alpha = ldexp(1.0, -9); live = false; }   // every step length tried
@@ -1211,6 +1224,13 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
         if (!done && a.list) {      // goes on: onto the next iteration's list (the order there is arbitrary; nothing depends on it)
             const int nxt = (a.iter + 1) & 1;
             a.list[(long)nxt * a.B + atomicAdd(a.count + nxt, 1)] = (int)b;
+            if (widen) sc[S_WIDE] = 1.0;
+            double now = 0.0;
+            if (a.wide && (widen || sc[S_WIDE] != 0.0)) {     // a place on the wide list while there are any
+                const int at = atomicAdd(a.wcount + nxt, 1);
+                if (at < kWideMax) { a.wide[nxt * kWideMax + at] = (int)b; now = 1.0; }
+            }
+            sc[S_WIDENOW] = now;
         }
         if (iters <= (double)kTraceIters) {
             double *tr = ws + L.trace + ((long)iters - 1) * kTraceDoubles;
@@ -1324,8 +1344,8 @@ hipError_t ik_launch_backward(const IkBatchArgs &a, hipStream_t st) {
 hipError_t ik_launch_forward(const IkBatchArgs &a, hipStream_t st) {
     const unsigned n = (unsigned)launch_problems(a);
     if (a.fwd_spec == 4) hipLaunchKernelGGL(ik_forward_kernel<3>, dim3(3 * n), dim3(192), 0, st, a);
-    else if (a.fwd_spec == 3) hipLaunchKernelGGL(ik_forward_kernel<3>, dim3(n), dim3(192), 0, st, a);
-    else if (a.fwd_spec) hipLaunchKernelGGL(ik_forward_kernel<2>, dim3(n), dim3(128), 0, st, a);
+    else if (a.fwd_spec == 3) hipLaunchKernelGGL(ik_forward_kernel<3>, dim3(n + (a.wide ? 2 * kWideMax : 0)), dim3(192), 0, st, a);
+    else if (a.fwd_spec) hipLaunchKernelGGL(ik_forward_kernel<2>, dim3(n + (a.wide ? 2 * kWideMax : 0)), dim3(128), 0, st, a);
     else hipLaunchKernelGGL(ik_forward_kernel<1>, dim3((n + 3) / 4), dim3(64), 0, st, a);
     return hipGetLastError();
 }

@@ -72,7 +72,15 @@ struct IkLayout {
     }
 };
 // scalars kept per problem in ws[scal + i]
-enum IkScal { S_COST = 0, S_XREG, S_D1, S_D2, S_STOP, S_FEAS, S_WASFEAS, S_DONE, S_ITERS, S_RECALC, S_STATUS, S_NODECOST };
+enum IkScal { S_COST = 0, S_XREG, S_D1, S_D2, S_STOP, S_FEAS, S_WASFEAS, S_DONE, S_ITERS, S_RECALC, S_STATUS, S_NODECOST,
+              S_WIDE,       // sticky: a line search of this problem once needed more than the four step lengths of one workgroup
+              S_WIDENOW };  // its next forward pass runs as three workgroups (it holds one of the kWideMax places of the wide list)
+// Problems whose line search goes past four step lengths are few and always the same ones (Go2 H = 60, 1024 problems: three
+// problems cause a second round in 76 of the 100 iterations), and a second round costs the whole batch a rollout's latency.
+// Such a problem is flagged (S_WIDE) and from then on gets all ten step lengths at once, on three workgroups.
+constexpr int kWideMax = 32;
+// ints of device scratch behind bmpc_ik_batch_t.active_list: list[2][B], count[2], wide_count[2], wide[2][kWideMax]
+inline long active_list_ints(long B) { return 2 * B + 4 + 2 * kWideMax; }
 
 struct IkBatchArgs {
     int B, T, maxiter;
@@ -83,6 +91,7 @@ struct IkBatchArgs {
     // lists of B problem indices + two counts: DDP iteration k works on list[k & 1][0 .. count[k & 1]) and its forward pass
     // appends the problems that go on to list[(k + 1) & 1].  n_launch (host side, one look behind) bounds count.
     int *list, *count;
+    int *wide, *wcount;        // the flagged problems among them (see kWideMax): wide[k & 1][0 .. min(wcount[k & 1], kWideMax))
     int iter, n_launch;
     const RobotModelDev *model;
     const double *x0;          // [B][37]

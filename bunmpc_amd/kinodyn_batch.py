@@ -40,7 +40,7 @@ class KinoDynDeviceBatch:
         self.trace_off, self.trace_iters, self.trace_width = t_off.value, t_it.value, t_w.value
         self.ws = torch.zeros((B, self.ws_doubles), dtype=f64, device=self.device)
         self.active = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self.active_list = torch.zeros(2 * B + 2, dtype=torch.int32, device=self.device)
+        self.active_list = torch.zeros(lib.bmpc_ik_active_list_ints(B), dtype=torch.int32, device=self.device)
         self.iters_run = C.c_int(0)
         d = _lib.KinoDynBatch()
         C.memmove(C.byref(d.dyn), C.byref(self.dyn.desc), C.sizeof(_lib.Batch))
@@ -81,6 +81,7 @@ class KinoDynDeviceBatch:
         sc = ws[:, o["scal"]:o["scal"] + 16]
         out["ik_cost"], out["ik_stop"] = sc[:, 0], sc[:, 4]
         out["ik_iters"], out["ik_status"] = sc[:, 8].astype(np.int64), sc[:, 10].astype(np.int64)
+        out["ik_wide_line_search"] = sc[:, 12] != 0     # flagged: ran its later line searches with all ten step lengths at once
         out["ddp_loop_iters"] = self.iters_run.value
         # rows [iteration][cost, regularisation, accepted step length (0 = none), |Q_u|^2]; rows past ik_iters are stale
         out["ik_trace"] = ws[:, self.trace_off:self.trace_off + self.trace_iters * self.trace_width].reshape(-1, self.trace_iters, self.trace_width)

@@ -219,11 +219,13 @@ typedef struct {
     int *active;
     int *iters_run;   /* host int or NULL: DDP iterations the loop executed */
     long s_x_reg, sn_state_w, sn_x_reg, sn_ctrl_w;   /* 0 = defaults: x_reg [B][37], one vector per problem */
-    int *active_list; /* device, 2 B + 2 ints of scratch, or NULL.  With it every launch of the DDP loop covers only the problems
-                         still iterating (an index list the forward pass rebuilds each iteration); without it every launch
-                         covers all B and finished problems return at once.  Results do not depend on it. */
+    int *active_list; /* device, bmpc_ik_active_list_ints(B) ints of scratch, or NULL.  With it every launch of the DDP loop covers
+                         only the problems still iterating (an index list the forward pass rebuilds each iteration), and the few
+                         problems whose line search goes past four step lengths get all ten at once from then on; without it
+                         every launch covers all B and finished problems return at once.  Results do not depend on it. */
 } bmpc_ik_batch_t;
 int bmpc_ik_batch_struct_size(void);     /* sizeof(bmpc_ik_batch_t), to catch binding drift */
+long bmpc_ik_active_list_ints(long B);   /* length of bmpc_ik_batch_t.active_list */
 int bmpc_ik_workspace_doubles(int n_col);
 void bmpc_ik_layout(int n_col, long *offsets8);      /* xs, us, scalars, K, k, fs, Lx, Lxx */
 /* telemetry: rows [iteration i < *iters][*width = 4] at *offset of a problem's workspace: cost, regularisation, accepted step

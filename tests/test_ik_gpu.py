@@ -232,6 +232,31 @@ def test_line_search_scheduling_does_not_change_results(model):
         assert np.array_equal(out[0]["ik_trace"][:, :1], o["ik_trace"][:, :1]) and n <= 100
 
 
+def test_wide_line_search_does_not_change_results():
+    """Go2 H = 60: problem 2 of the bench batch is one of the three whose line search keeps going past four step lengths (the
+    CPU twin's trace: 54 of its 100 iterations).  With the active list such a problem is flagged at the first occurrence and
+    from then on tries all ten step lengths at once on three workgroups; without the list it goes through the rounds of four.
+    Same decisions, same bits."""
+    import dataclasses
+    from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
+    go2 = urdf_model.RobotModel.from_json(open(ROBOT.replace("solo12.json", "go2.json")).read())
+    wb = problems.make_wb_batch(go2, 6, gait=dataclasses.replace(problems.TROT, nom_ht=0.30, gait_horizon=6.0), wb=problems.GO2_WB)
+    out = []
+    for use_list in (True, False):
+        kb = KinoDynDeviceBatch(wb, go2, num_iters=10, use_active_list=use_list)
+        kb.solve()
+        out.append(kb.results())
+    a, b = out
+    assert a["ik_wide_line_search"][2] and not b["ik_wide_line_search"].any()
+    tr = a["ik_trace"][2, :100, 2]
+    assert a["ik_iters"][2] == 100 and ((tr > 0) & (tr < 2.0 ** -3.5)).sum() > 20       # accepted step lengths below 1/8: past the first four
+    for k in ("ik_iters", "ik_status", "xs", "us", "ik_cost", "ik_stop"):
+        assert np.array_equal(a[k], b[k]), k
+    n = a["ik_iters"]
+    for i in range(6):
+        assert np.array_equal(a["ik_trace"][i, :n[i]], b["ik_trace"][i, :n[i]])
+
+
 def test_ik_longest_horizon(model):
     """n_col = 63 (the largest the kernels take: T + 1 = 64 nodes): regularisation + one foot target per node, the
     numpy DDP on the same problem as the reference"""

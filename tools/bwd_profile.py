@@ -5,9 +5,14 @@ sys.path.insert(0, ".")
 import numpy as np, torch
 from bunmpc_amd import problems, urdf_model
 from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
-model = urdf_model.RobotModel.from_json(open("bunmpc_amd/robots/solo12.json").read())
-for B in (1, 4096):
-    wb = problems.make_wb_batch(model, B)
+import dataclasses
+robot = sys.argv[1] if len(sys.argv) > 1 else "solo12"      # solo12 (H = 20, H_ik = 10) | go2 (H = 60, H_ik = 30)
+model = urdf_model.RobotModel.from_json(open("bunmpc_amd/robots/%s.json" % robot).read())
+for B in ((1, 4096) if robot == "solo12" else (1, 1024)):
+    if robot == "go2":
+        wb = problems.make_wb_batch(model, B, gait=dataclasses.replace(problems.TROT, nom_ht=0.30, gait_horizon=6.0), wb=problems.GO2_WB)
+    else:
+        wb = problems.make_wb_batch(model, B)
     kb = KinoDynDeviceBatch(wb, model, num_iters=10)
     kb.solve(); r = kb.results()
     T = wb.ik_T
