@@ -435,7 +435,7 @@ def biconvex_leg(D, args):
                    "global_batch": B * W, "parallelism": "batch-shard x%d" % W},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(wkey),
-                     "kernel": "biconvex_admm_kernel<%s>" % ("double" if args.precision == "f64" else "float"), "kernel_ms": kern_ms,
+                     "kernel": "biconvex_admm_kernel<double>" if args.precision == "f64" else "biconvex_admm_kernel_f32", "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_launch": abytes,
                      "valu": {"model_flops_per_launch": flops,
                               "achieved_tflops": flops / (kern_ms * 1e-3) / 1e12,

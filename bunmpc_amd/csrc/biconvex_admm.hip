@@ -497,13 +497,18 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
     }
 }
 
-// Two waves per SIMD (256 registers each).  The body wants 284-307 (fp32) / 314-370 (fp64) registers, so the cap moves the
-// coldest 40-90 values to scratch (150-370 B per lane, outside the FISTA loops); in exchange each wave's dependent-latency
-// stalls are filled by the other.  Measured at B = 4096 on MI355X: fp32 Go2 H=40 9.0 -> 7.1 ms, fp64 Solo12 H=20 4.33 -> 4.17 ms,
-// fp64 Go2 H=40 9.8 -> 9.56 ms (the fp64 loop is bound by the half-rate fp64 VALU, the fp32 one by latency).
+// fp64: ONE wave per SIMD.  The body holds 314-370 registers; capped at 256 (two waves per SIMD) the compiler parks 60-90
+// values in scratch memory and the launch is 4 % faster (4.33 -> 4.17 ms at B = 4096) -- but the scratch of 2048 waves does
+// not stay in L2 and the kernel's HBM traffic goes from 39.5 MB (the inputs once, the results once) to 549 MB per launch
+// (PMC, FETCH_SIZE x 2 + WRITE_SIZE).  Not taken: the iterates-never-leave-the-chip property is worth more than 4 %.
 template <typename R, int LPP, int E, bool RAW, bool HASQF>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void biconvex_admm_kernel(const BatchArgs a) {
-    admm_body<R, LPP, E, RAW, HASQF>(a);
+__global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) { admm_body<R, LPP, E, RAW, HASQF>(a); }
+// fp32 (BASELINE config 3): the body wants 284-307 registers, so the cap of TWO waves per SIMD costs 40-60 spilled values
+// (150-240 B per lane) and buys what this latency-bound loop lacks: a second wave to issue from while the first waits
+// (Go2 H = 40, B = 4096: 9.0 -> 7.1 ms).
+template <int LPP, int E>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void biconvex_admm_kernel_f32(const BatchArgs a) {
+    admm_body<float, LPP, E, false, false>(a);
 }
 
 __global__ __launch_bounds__(64) void lane_selftest_kernel(const double *in, double *out) {
@@ -523,7 +528,8 @@ hipError_t launch(const BatchArgs &a, hipStream_t stream) {
     const unsigned grid = (unsigned)((a.B + per_wave - 1) / per_wave);
     const size_t nstate = 2 * 9 * (size_t)(a.H + 1) + 12 * (size_t)a.H;   // X, P, F of one problem
     const size_t lds = sizeof(R) * ((((size_t)a.c.maxit + 1) & ~(size_t)1) + per_wave * nstate);
-    hipLaunchKernelGGL((biconvex_admm_kernel<R, LPP, 4, RAW, HASQF>), dim3(grid), dim3(64), lds, stream, a);
+    if (sizeof(R) == sizeof(float)) hipLaunchKernelGGL((biconvex_admm_kernel_f32<LPP, 4>), dim3(grid), dim3(64), lds, stream, a);
+    else hipLaunchKernelGGL((biconvex_admm_kernel<double, LPP, 4, RAW, HASQF>), dim3(grid), dim3(64), lds, stream, a);
     return hipGetLastError();
 }
 
