@@ -175,6 +175,7 @@ _SIGS = {
     "bmpc_ik_selftest_state_ops": (_I, [_P, _P, _P, _I, _P, _P, _P, _P]),
     "bmpc_ik_set_profile": (_I, [_I]),
     "bmpc_ik_set_all_steps": (_I, [_I]),
+    "bmpc_ik_set_gains_wave_below": (_I, [_I]),
     "bmpc_ik_batch_struct_size": (_I, []),
     "bmpc_ik_active_list_ints": (C.c_long, [C.c_long]),
     "bmpc_ik_last_profile": (None, [_P]),

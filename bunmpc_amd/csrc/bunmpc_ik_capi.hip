@@ -147,7 +147,7 @@ bunmpc::IkBatchArgs make_args(int B, int T, int maxiter, const bmpc_model *model
     a.B = B; a.T = T; a.maxiter = maxiter; a.model = model->dptr();
     a.x0 = x0; a.dt = dt; a.tasks = tasks; a.state_w = state_w; a.x_reg = x_reg; a.ctrl_w = ctrl_w;
     a.s_state_w = s_sw; a.s_ctrl_w = s_cw; a.ws = ws; a.active = active;
-    a.s_x_reg = bunmpc::kNX; a.sn_state_w = a.sn_x_reg = a.sn_ctrl_w = 0; a.fwd_spec = 0;
+    a.s_x_reg = bunmpc::kNX; a.sn_state_w = a.sn_x_reg = a.sn_ctrl_w = 0; a.fwd_spec = 0; a.bwd_waves = 1;
     a.list = nullptr; a.count = nullptr; a.wide = nullptr; a.wcount = nullptr; a.iter = 0; a.n_launch = B;
     return a;
 }
@@ -159,6 +159,8 @@ int g_spec_line_search_below = 1024;
 int g_all_steps = 0;              // at most this many active problems: all ten step lengths at once, three workgroups per problem
                                   // (0 = never, the default: measured on the MI355X it gains < 1 % on the Go2 H = 60 batch at <= 85 -- one workgroup of
                                   // three waves per CU is the forward kernel's residency -- and loses 2 % on Solo12)
+int g_gains_wave_below = 512;     // at most this many active problems: the backward pass gives each a second wave for the gains
+                                  // (two waves per problem on the MI355X's 1024 SIMDs; no effect on results)
 constexpr int kMaxIkCol = 63;     // T + 1 <= 64 nodes: the backward pass computes the gaps one lane per node
 
 // Two host-mapped words and events per (device, stream), through which the kernels' active counter reaches the DDP loop.
@@ -228,6 +230,7 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run) {
     auto enqueue_chunk = [&](int slot) -> int {
         const int chunk = active <= g_spec_line_search_below ? kTailChunk : 1;
         a.fwd_spec = active <= g_all_steps ? 4 : active <= g_spec_line_search_below / 3 ? 3 : active <= g_spec_line_search_below ? 2 : 0;
+        a.bwd_waves = active <= g_gains_wave_below ? 2 : 1;
         a.n_launch = active;        // the host's latest look at the counter: an upper bound of the active list's length
         for (int k = 0; k < chunk && it < a.maxiter; ++k, ++it) {
             a.iter = it;
@@ -662,6 +665,7 @@ void bmpc_ik_layout(int n_col, long *offsets8) {   // xs, us, scal, K, kff, fs, 
     offsets8[5] = L.fs; offsets8[6] = L.Lx; offsets8[7] = L.Lxx;
 }
 
+int bmpc_ik_set_gains_wave_below(int n_active) { const int old = g_gains_wave_below; g_gains_wave_below = n_active; return old; }
 long bmpc_ik_active_list_ints(long B) { return bunmpc::active_list_ints(B); }
 
 void bmpc_ik_layout_trace(int n_col, long *offset, int *iters, int *width) {   // the per-iteration telemetry rows of a problem's workspace

@@ -533,13 +533,19 @@ __device__ __forceinline__ double rcp64(double b) {
     return fma(fma(-b, r, 1.0), r, r);
 }
 
+// NB = 2 (the two-wave kernel): what the gains wave needs of a node -- the factor, Y^T, y_u, the reciprocal pivots, Q_u -- is
+// double-buffered, node t in buffer t & 1 of the pass' running count, so the recursion writes node t - 1 while the gains of
+// node t are still being read.
+template <int NB>
 struct alignas(16) BackwardLds {
     double N[kPadRows * LD + 16];   // row-major staging: N = F_x^T V for the transposition, later Q_xx -> V_xx rows
-    double Ys[kPadRows * LDK];      // Y^T, Y = L^-1 Q_ux (36 x 18 in a zeroed 48 x 21 image): both operands of the Schur update
-    double Lc[5 * 36];              // Cholesky factor packed by rows (L[p][q], q < p, at p(p-1)/2 + q), read back by broadcast in
+    double Ys[NB][kPadRows * LDK];  // Y^T, Y = L^-1 Q_ux (36 x 18 in a zeroed 48 x 21 image): both operands of the Schur update
+    double Lc[NB][5 * 36];          // Cholesky factor packed by rows (L[p][q], q < p, at p(p-1)/2 + q), read back by broadcast in
                                     // batches of 36
     double A6[36], B6[36];
     double Vx[kNDX], fs[kNDX];
+    double yu[NB][kNV + 2], idg[NB][kNV + 2], qu[NB][kNV + 2];     // y_u = L^-1 Q_u, 1 / L[p][p], Q_u   (gains wave only)
+    int tnode[NB];                  // which node the buffer holds; -1: the pass is over
 };
 
 // x <- F_x^T x for a 36-vector held by one lane, in place: only x[0..5] feed more than one output.
@@ -571,11 +577,57 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-__global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
-    __shared__ BackwardLds s;
+// NWB = 2 (few problems still iterating): the gains K = L^-T Y, k = L^-T y_u -- the back substitutions, their
+// stores and the terms of the expected improvement that need k -- are for the forward pass, not for the next node of the
+// recursion (V_xx = Q_xx - Y^T Y and V_x = Q_x - Y^T y_u come from the forward substitutions alone).  A second wave takes
+// them over, one node behind: the recursion hands it the factor and Y through LDS and goes on.
+__device__ __forceinline__ void bwd_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// the gains wave of the two-wave backward pass
+__device__ __forceinline__ void backward_gains_wave(BackwardLds<2> &s, double *ws, double *sc, const IkLayout &L, int T, int lane) {
+    const bool row = lane < kNDX;
+    double d1 = 0.0, st = 0.0;
+    for (int k = 0;; ++k) {
+        bwd_barrier();
+        const int buf = k & 1, t = s.tnode[buf];
+        if (t < 0) break;
+        if (t == T - 1) { d1 = 0.0; st = 0.0; }      // first node of a pass (a pass that failed is started again)
+        double y[kNV], idg[kNV], quv[kNV];
+        {
+            const double *src = row ? s.Ys[buf] + lane * LDK : s.yu[buf];
+            UNROLL_RBD for (int p = 0; p < kNV; ++p) y[p] = src[p];
+            UNROLL_RBD for (int p = 0; p < kNV; ++p) { idg[p] = s.idg[buf][p]; quv[p] = s.qu[buf][p]; }      // (this wave has time)
+        }
+        {   // back substitution L^T k = y, column by column (as in the one-wave kernel)
+            const unsigned lc_addr = lds_offset(s.Lc[buf]);
+            double2_t lb[18];
+            int cur = -1;
+            UNROLL_RBD for (int p = kNV - 1; p >= 0; --p) {
+                y[p] *= idg[p];
+                UNROLL_RBD for (int q = p - 1; q >= 0; --q) {
+                    const int idx = p * (p - 1) / 2 + q, bb = idx / 36, e = idx % 36;
+                    if (bb != cur) { lds_read_b128x18(lc_addr + (unsigned)bb * 288, lb); cur = bb; }
+                    y[q] -= ((e & 1) ? lb[e >> 1].y : lb[e >> 1].x) * y[p];
+                }
+            }
+        }
+        UNROLL_RBD for (int p = 0; p < kNV; ++p) { d1 += quv[p] * y[p]; st += quv[p] * quv[p]; }   // d1 = Qu.k, stop = |Qu|^2
+        if (row) {
+            double *Kg = ws + L.K + (long)t * kNV * kNDX + lane;
+            UNROLL_RBD for (int p = 0; p < kNV; ++p) { Kg[p * kNDX] = y[p]; asm volatile("" ::: "memory"); }
+        } else if (lane == kQuLane) {
+            UNROLL_RBD for (int p = 0; p < kNV; ++p) ws[L.kff + (long)t * kNV + p] = y[p];
+        }
+    }
+    if (lane == kQuLane) { sc[S_D1] = d1; sc[S_STOP] = st; }
+}
+
+template <int NWB>
+__global__ __launch_bounds__(64 * NWB) void ik_backward_kernel(const IkBatchArgs a) {
+    __shared__ BackwardLds<NWB> s;
     const long b = slot_problem(a, blockIdx.x);
     if (b < 0) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const IkLayout L = IkLayout::make(a.T);
     double *ws = a.ws + b * L.total;
     double *sc = ws + L.scal;
@@ -583,8 +635,10 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
     const int T = a.T;
     bool feas = sc[S_FEAS] != 0.0;
     const bool wasfeas = sc[S_WASFEAS] != 0.0;
-    for (int i = lane; i < kPadRows * LDK; i += 64) s.Ys[i] = 0.0;                         // the padding of the MFMA operand image
+    if (NWB == 2 && threadIdx.x >= 64) { backward_gains_wave(reinterpret_cast<BackwardLds<2> &>(s), ws, sc, L, a.T, lane); return; }
+    for (int i = lane; i < NWB * kPadRows * LDK; i += 64) s.Ys[0][i] = 0.0;                  // the padding of the MFMA operand image(s)
     for (int i = kNDX * LD + lane; i < kPadRows * LD + 16; i += 64) s.N[i] = 0.0;
+    int hand = 0;       // NWB = 2: nodes handed to the gains wave so far (buffer = hand & 1)
 
     if (sc[S_RECALC] != 0.0) {
         // SolverDDP::calcDiff tail: total cost and the gaps fs
@@ -697,7 +751,8 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             // column), and the NEXT pivot's is started as soon as its entry has had this pivot's update -- before the rest of
             // the trailing update, whose independent instructions then fill the waits of that dependent chain.
             double idg[kNV];
-            double rs;
+            double rs, mydg = 0.0;
+            const int buf = NWB == 2 ? (hand & 1) : 0;      // the hand-over buffer of this node
             {
                 const double piv = lane_value(al[0], kNDX) + lane_value(dgv, kNDX);
                 if (!(piv > 0.0)) bad = true;
@@ -705,6 +760,7 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             }
             UNROLL_RBD for (int j = 0; j < kNV; ++j) {
                 idg[j] = rs;
+                if (NWB == 2) mydg = lane == kNDX + j ? rs : mydg;      // 1 / L[j][j] stays on the lane of row j (one select, no branch)
                 const double f = al[j] * (rs * rs);
                 double rs_next = 0.0;
                 if (j + 1 < kNV) {
@@ -723,18 +779,34 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             if (urow) {      // row p of L (its p entries left of the diagonal) is at hand on lane 36 + p: packed by rows
                 const int p = lane - kNDX;
                 UNROLL_RBD for (int q = 0; q < kNV - 1; ++q) {
-                    if (q < p) s.Lc[p * (p - 1) / 2 + q] = al[q];
+                    if (q < p) s.Lc[buf][p * (p - 1) / 2 + q] = al[q];
                 }
             }
             double (&y)[kNV] = al;
-            // expectedImprovement / stoppingCriteria ingredients (lane 54): d2 = -k.Quu k = -|L^T k|^2 = -|L^-1 Qu|^2
-            UNROLL_RBD for (int p = 0; p < kNV; ++p) d2 -= y[p] * y[p];
+            // expectedImprovement / stoppingCriteria ingredients (lane 54): d2 = -k.Quu k = -|L^T k|^2 = -|L^-1 Qu|^2; and
+            // V_x = Q_x - K^T Q_u = Q_x - Y^T y_u (K = L^-T Y, y_u = L^-1 Q_u on lane 54): from the forward substitutions alone, like
+            // V_xx -- the recursion does not wait for the gains
+            auto improvement_and_vx = [&]() {
+                UNROLL_RBD for (int p = 0; p < kNV; ++p) d2 -= y[p] * y[p];
+                double w = qx;
+                UNROLL_RBD for (int p = 0; p < kNV; ++p) w -= y[p] * lane_value(y[p], kQuLane);
+                vx = w;
+            };
             // Y = L^-1 Q_ux (column j on lane j) is all the Riccati recursion needs: Q_xu K = Q_xu Q_uu^-1 Q_ux = Y^T Y.  It goes to
             // LDS as the one operand image of the Schur update; the gains K = L^-T Y (back substitution) are for the forward pass,
             // not for the next node.  The MFMAs are issued after the substitution (their accumulators would not fit beside its
             // registers) and before the stores of K, V_x and the improvement terms, which the vector pipe does while the matrix
             // pipe works through its tiles.
-            if (row) { UNROLL_RBD for (int p = 0; p < kNV; ++p) s.Ys[r * LDK + p] = y[p]; }
+            if (NWB == 2) {     // ... and y_u, the reciprocal pivots and Q_u for the gains wave, in the same instructions where possible
+                double *dst = row ? s.Ys[buf] + r * LDK : s.yu[buf];
+                if (row || lane == kQuLane) { UNROLL_RBD for (int p = 0; p < kNV; ++p) dst[p] = y[p]; }
+                if (urow) s.idg[buf][lane - kNDX] = mydg;
+                if (ul) s.qu[buf][uq] = qu;
+                if (lane == 0) s.tnode[buf] = t;
+            } else {
+                if (row) { UNROLL_RBD for (int p = 0; p < kNV; ++p) s.Ys[buf][r * LDK + p] = y[p]; }
+                improvement_and_vx();
+            }
             wave_sync();
             // V_xx = Q_xx - Y^T Y on the matrix pipe (layouts at BackwardLds): fp64 MFMA has the vector FMA rate on gfx950, so this
             // is not about flops -- one MFMA replaces 16 wave-wide FMAs in the issue stream, and every lane feeds ONE element of
@@ -742,9 +814,9 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             // ds_read_b128 of the vector version).  The product is symmetric and V_xx is symmetrised right after: only the six
             // tiles on and above the block diagonal are computed (independent accumulators, k outermost); an off-diagonal tile is
             // stored a second time, transposed, where its mirror image belongs.
-            {   // back substitution L^T k = y, column by column: once k_p is final its multiples leave all earlier equations --
+            if (NWB == 1) {   // back substitution L^T k = y, column by column: once k_p is final its multiples leave all earlier equations --
                 // independent updates (the row form accumulated each k_p through a chain of dependent FMAs)
-                const unsigned lc_addr = lds_offset(s.Lc);
+                const unsigned lc_addr = lds_offset(s.Lc[0]);
                 double2_t lb[18];
                 int cur = -1;
                 UNROLL_RBD for (int p = kNV - 1; p >= 0; --p) {
@@ -761,7 +833,7 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
             mfma_acc_t acc[6];
             {
                 double bv[15], c[24];
-                lds_read_mfma_operand(lds_offset(s.Ys + li * LDK + lk), bv);
+                lds_read_mfma_operand(lds_offset(s.Ys[buf] + li * LDK + lk), bv);
                 lds_read_mfma_acc_upper(lds_offset(s.N + lk * LD + li), c);
                 UNROLL_RBD for (int tl = 0; tl < 6; ++tl)
                     UNROLL_RBD for (int v = 0; v < 4; ++v) acc[tl][v] = c[4 * tl + v];
@@ -772,18 +844,18 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
                             acc[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-bv[5 * I + ks], bv[5 * J + ks], acc[tl], 0, 0, 0);
                         }
             }
-            UNROLL_RBD for (int p = 0; p < kNV; ++p) { d1 += quv[p] * y[p]; st += quv[p] * quv[p]; }   // d1 = Qu.k, stop = |Qu|^2
-            if (row) {      // (the empty asm keeps the stores in program order: clustered, hipcc spills a hundred registers around them)
-                double *Kg = ws + L.K + (long)t * kNV * kNDX + r;
-                UNROLL_RBD for (int p = 0; p < kNV; ++p) { Kg[p * kNDX] = y[p]; asm volatile("" ::: "memory"); }
-            } else if (lane == kQuLane) {
-                UNROLL_RBD for (int p = 0; p < kNV; ++p) ws[L.kff + (long)t * kNV + p] = y[p];
-            }
-            // V_x = Q_x - K^T Q_u
-            {
-                double w = qx;
-                UNROLL_RBD for (int p = 0; p < kNV; ++p) w -= y[p] * quv[p];
-                vx = w;
+            if (NWB == 2) {     // while the matrix pipe works through the tiles; then the node is the gains wave's
+                improvement_and_vx();
+                bwd_barrier();
+                ++hand;
+            } else {
+                UNROLL_RBD for (int p = 0; p < kNV; ++p) { d1 += quv[p] * y[p]; st += quv[p] * quv[p]; }   // d1 = Qu.k, stop = |Qu|^2
+                if (row) {      // (the empty asm keeps the stores in program order: clustered, hipcc spills a hundred registers around them)
+                    double *Kg = ws + L.K + (long)t * kNV * kNDX + r;
+                    UNROLL_RBD for (int p = 0; p < kNV; ++p) { Kg[p * kNDX] = y[p]; asm volatile("" ::: "memory"); }
+                } else if (lane == kQuLane) {
+                    UNROLL_RBD for (int p = 0; p < kNV; ++p) ws[L.kff + (long)t * kNV + p] = y[p];
+                }
             }
             PSTAMPV(6, vx)
             UNROLL_RBD for (int I = 0; I < 3; ++I)
@@ -827,13 +899,18 @@ __global__ __launch_bounds__(64) void ik_backward_kernel(const IkBatchArgs a) {
         if (lane == 0) { sc[S_XREG] = xreg; sc[S_RECALC] = 0.0; }
         if (xreg == 1e9) {
             if (lane == 0) { sc[S_DONE] = 1.0; sc[S_STATUS] = 2.0; atomicSub(a.active, 1); }
+            if (NWB == 2) { if (lane == 0) s.tnode[hand & 1] = -1; bwd_barrier(); }
             return;
         }
     }
 #ifdef BWD_PROFILE
     if (lane == 0) { for (int k = 0; k < 9; ++k) ws[L.Quuk + k] = (double)pc[k]; }   // the Quuk slot is unused by the solver
 #endif
-    if (lane == kQuLane) { sc[S_D1] = d1; sc[S_D2] = d2; sc[S_STOP] = st; }   // the lane of the feed-forward terms
+    if (NWB == 2) {     // the pass is over: the gains wave writes d1 and the stopping criterion on its way out
+        if (lane == 0) s.tnode[hand & 1] = -1;
+        bwd_barrier();
+        if (lane == kQuLane) sc[S_D2] = d2;
+    } else if (lane == kQuLane) { sc[S_D1] = d1; sc[S_D2] = d2; sc[S_STOP] = st; }   // the lane of the feed-forward terms
 }
 
 // ---------------------------------------------------------------------------- forward ---
@@ -1338,7 +1415,8 @@ hipError_t ik_launch_calcdiff(const IkBatchArgs &a, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t ik_launch_backward(const IkBatchArgs &a, hipStream_t st) {
-    hipLaunchKernelGGL(ik_backward_kernel, dim3((unsigned)launch_problems(a)), dim3(64), 0, st, a);
+    if (a.bwd_waves == 2) hipLaunchKernelGGL(ik_backward_kernel<2>, dim3((unsigned)launch_problems(a)), dim3(128), 0, st, a);
+    else hipLaunchKernelGGL(ik_backward_kernel<1>, dim3((unsigned)launch_problems(a)), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 hipError_t ik_launch_forward(const IkBatchArgs &a, hipStream_t st) {

@@ -90,6 +90,7 @@ struct IkBatchArgs {
     // Active-problem list (or null: every launch covers all B problems, finished ones return at once).  Two ping-pong
     // lists of B problem indices + two counts: DDP iteration k works on list[k & 1][0 .. count[k & 1]) and its forward pass
     // appends the problems that go on to list[(k + 1) & 1].  n_launch (host side, one look behind) bounds count.
+    int bwd_waves;             // backward pass: 1 = one wave per problem; 2 = a second wave for the gains (few active problems)
     int *list, *count;
     int *wide, *wcount;        // the flagged problems among them (see kWideMax): wide[k & 1][0 .. min(wcount[k & 1], kWideMax))
     int iter, n_launch;

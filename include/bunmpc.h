@@ -238,6 +238,9 @@ void bmpc_ik_layout_trace(int n_col, long *offset, int *iters, int *width);
  * the old value. */
 int bmpc_ik_set_speculative_below(int n_active);
 int bmpc_ik_set_all_steps(int n_active);
+/* Riccati-pass scheduling (no effect on results): while at most n_active problems are still iterating, each gets a second
+ * wave that computes and stores the gains K, k one node behind the recursion.  Default 512; 0 = never.  Returns the old value. */
+int bmpc_ik_set_gains_wave_below(int n_active);
 int bmpc_ik_solve_batch_device(const bmpc_ik_batch_t *d, void *hip_stream);
 /* Measurement aid (additive): with profiling on, the DDP loop brackets each of its kernels with events; after a batch solve
  * bmpc_ik_last_profile returns the summed milliseconds of ik_state / ik_calcdiff / ik_backward / ik_forward and of the rest

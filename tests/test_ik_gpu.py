@@ -205,31 +205,36 @@ def test_kinodyn_batch_go2_h60(oracle):
 def test_line_search_scheduling_does_not_change_results(model):
     """How the batched DDP is scheduled must not show in its results: step lengths one after the other (four problems per
     wave), four at a time (one problem per workgroup) or all ten at once (three workgroups per problem, the last to arrive
-    decides) -- SolverDDP's decision, the first passing step length in its order, is the same; and launches over the
-    active-problem list or over all B problems touch the same problems."""
+    decides) -- SolverDDP's decision, the first passing step length in its order, is the same; launches over the
+    active-problem list or over all B problems touch the same problems; and the Riccati pass on one wave per problem or with
+    a second wave for the gains does the same arithmetic."""
     from bunmpc_amd import _lib
     from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
     lib = _lib.lib()
     wb = problems.make_wb_batch(model, 9)
     out = []
-    old, old_all = lib.bmpc_ik_set_speculative_below(0), lib.bmpc_ik_set_all_steps(0)
+    old, old_all, old_gw = lib.bmpc_ik_set_speculative_below(0), lib.bmpc_ik_set_all_steps(0), lib.bmpc_ik_set_gains_wave_below(0)
     try:
-        for below, all_steps, use_list in ((0, 0, True), (1 << 30, 0, True), (1 << 30, 1 << 30, True), (0, 0, False), (1 << 30, 1 << 30, False), (6, 3, True)):
+        for below, all_steps, use_list, gains in ((0, 0, True, 0), (1 << 30, 0, True, 0), (1 << 30, 1 << 30, True, 1 << 30), (0, 0, False, 1 << 30),
+                                                  (1 << 30, 1 << 30, False, 0), (6, 3, True, 4)):
             lib.bmpc_ik_set_speculative_below(below)
             lib.bmpc_ik_set_all_steps(all_steps)
+            lib.bmpc_ik_set_gains_wave_below(gains)
             kb = KinoDynDeviceBatch(wb, model, num_iters=10, use_active_list=use_list)
             kb.solve()
             out.append(kb.results())
     finally:
         lib.bmpc_ik_set_speculative_below(old)
         lib.bmpc_ik_set_all_steps(old_all)
+        lib.bmpc_ik_set_gains_wave_below(old_gw)
     assert np.all(out[0]["ik_status"] == 0) and len(set(out[0]["ik_iters"].tolist())) > 1      # problems finish at different iterations
     for o in out[1:]:
         assert np.array_equal(out[0]["ik_iters"], o["ik_iters"])
         assert np.array_equal(out[0]["xs"], o["xs"]) and np.array_equal(out[0]["us"], o["us"])
-        assert np.array_equal(out[0]["ik_cost"], o["ik_cost"])
-        n = int(out[0]["ik_iters"].max())
-        assert np.array_equal(out[0]["ik_trace"][:, :1], o["ik_trace"][:, :1]) and n <= 100
+        assert np.array_equal(out[0]["ik_cost"], o["ik_cost"]) and np.array_equal(out[0]["ik_stop"], o["ik_stop"])
+        n = out[0]["ik_iters"]
+        for i in range(len(n)):
+            assert np.array_equal(out[0]["ik_trace"][i, :n[i]], o["ik_trace"][i, :n[i]])
 
 
 def test_wide_line_search_does_not_change_results():
@@ -241,11 +246,18 @@ def test_wide_line_search_does_not_change_results():
     from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
     go2 = urdf_model.RobotModel.from_json(open(ROBOT.replace("solo12.json", "go2.json")).read())
     wb = problems.make_wb_batch(go2, 6, gait=dataclasses.replace(problems.TROT, nom_ht=0.30, gait_horizon=6.0), wb=problems.GO2_WB)
+    from bunmpc_amd import _lib
+    lib = _lib.lib()
     out = []
-    for use_list in (True, False):
-        kb = KinoDynDeviceBatch(wb, go2, num_iters=10, use_active_list=use_list)
-        kb.solve()
-        out.append(kb.results())
+    old_gw = lib.bmpc_ik_set_gains_wave_below(512)
+    try:
+        for use_list, gains in ((True, 512), (False, 0)):      # ... and with / without the gains wave of the Riccati pass (a pass that fails
+            lib.bmpc_ik_set_gains_wave_below(gains)            # on a pivot and is started again at a larger regularisation occurs in these problems)
+            kb = KinoDynDeviceBatch(wb, go2, num_iters=10, use_active_list=use_list)
+            kb.solve()
+            out.append(kb.results())
+    finally:
+        lib.bmpc_ik_set_gains_wave_below(old_gw)
     a, b = out
     assert a["ik_wide_line_search"][2] and not b["ik_wide_line_search"].any()
     tr = a["ik_trace"][2, :100, 2]
@@ -255,6 +267,51 @@ def test_wide_line_search_does_not_change_results():
     n = a["ik_iters"]
     for i in range(6):
         assert np.array_equal(a["ik_trace"][i, :n[i]], b["ik_trace"][i, :n[i]])
+
+
+def test_riccati_pass_that_fails_and_restarts(model):
+    """A negative state weight makes Q_uu indefinite: computeDirection's Cholesky meets a non-positive pivot, raises the
+    regularisation and starts the pass again (solver-ddp.cpp solve()), possibly up to reg_max (status 2).  With the gains wave
+    the recursion has to call it back from wherever it is; both mappings must agree bit for bit, and with the compiled twin
+    on what happened."""
+    import dataclasses
+    from bunmpc_amd import _lib
+    from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
+    from oracle import ik_oracle_c as ic
+    lib = _lib.lib()
+    wb = problems.make_wb_batch(model, 6)
+    sw = wb.state_w.copy()
+    sw[0, 24:30] = -40.0         # leg joint velocities rewarded instead of penalised
+    wb = dataclasses.replace(wb, state_w=sw)
+    out = []
+    old_gw = lib.bmpc_ik_set_gains_wave_below(0)
+    try:
+        for gains in (0, 1 << 30):
+            lib.bmpc_ik_set_gains_wave_below(gains)
+            kb = KinoDynDeviceBatch(wb, model, num_iters=10)
+            kb.solve()
+            out.append(kb.results())
+    finally:
+        lib.bmpc_ik_set_gains_wave_below(old_gw)
+    a, b = out
+    n = a["ik_iters"]
+    reg = [a["ik_trace"][i, :n[i], 1] for i in range(6)]
+    assert any((r[1:] > 5 * r[:-1]).any() for r in reg if len(r) > 1) or (a["ik_status"] == 2).any()     # the regularisation did go up
+    for k in ("ik_iters", "ik_status", "xs", "us", "ik_cost", "ik_stop"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    for i in range(6):
+        assert np.array_equal(a["ik_trace"][i, :n[i]], b["ik_trace"][i, :n[i]], equal_nan=True)
+    # the problem is unbounded below (the cost runs off to -1e7) and the two implementations part ways by rounding after ~30
+    # iterations; up to there they must have taken the same decisions: regularisation (incl. the failed passes' increases),
+    # accepted step lengths, costs
+    tw = ic.solve_wb_batch(ic.Model(model), wb, a["X"], trace=True)
+    K = 18
+    for i in range(6):
+        g, t = a["ik_trace"][i, :K], tw["trace"][i, :K]
+        assert n[i] >= K and tw["iters"][i] >= K
+        assert np.array_equal(g[:, 1], t[:, 1]) and np.array_equal(g[:, 2], t[:, 2]), (i, g[:, 1:3], t[:, 1:3])
+        assert np.all(np.abs(g[:, 0] - t[:, 0]) <= 1e-6 * np.abs(t[:, 0]))
+        assert (g[:, 1] > 1e-2).any()        # within the compared prefix the regularisation has already gone up
 
 
 def test_ik_longest_horizon(model):
