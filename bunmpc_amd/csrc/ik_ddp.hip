@@ -7,18 +7,22 @@
 // crocoddyl::SolverDDP::solve() with all defaults.  crocoddyl 1.9.0 / pinocchio 2.6.9 are third
 // party and absent: semantics follow oracle/ik_ddp_np.py (PARITY UNPINNED).
 //
-// MI355X organisation (nothing like crocoddyl's object graph): three kernels per DDP iteration over
-// the whole batch, all per-problem state in one contiguous HBM workspace (IkLayout):
+// MI355X organisation (nothing like crocoddyl's object graph): four kernels per DDP iteration over the problems still
+// iterating (an active list the forward pass rebuilds), all per-problem state in one contiguous HBM workspace (IkLayout):
+//   ik_state_kernel     one LANE per (problem, node): the scalar chains of the derivative pass (state residual with its Jlog6
+//                       block, Euler step with its Jintegrate blocks, node cost parts) ahead of ik_calcdiff_kernel.
 //   ik_calcdiff_kernel  TWO waves per (problem, node): wave 0 walks the robot once (lane = velocity column, part sums
 //                       through LDS), wave 1 does the state residual / Euler step Jacobians meanwhile; both then
 //                       assemble the Gauss-Newton L_x / L_xx by column (coalesced 10 KB store).
 //   ik_backward_kernel  one WAVE per problem, matrix rows in registers (lane r = row r of V, G, Q_xx), exploiting
 //                       F_x = [[A, dt B],[0, I]], F_u = dt F_x[:, v] (A, B identity except a 6x6 free-flyer block):
 //                       G = F_x^T V F_x via one LDS transposition, Cholesky in registers over v_readlane, the gain
-//                       solves and V_xx = Q_xx - Q_xu K against broadcast LDS reads; regularisation retries
-//                       inside the kernel (details above the kernel).
+//                       solves against broadcast LDS reads, V_xx = Q_xx - Y^T Y on the matrix pipe; regularisation retries
+//                       inside the kernel (details above the kernel).  <2>: a second wave per problem computes and stores
+//                       the gains one node behind the recursion (few problems left).
 //   ik_forward_kernel   FOUR problems per wave (16 lanes each), or four step lengths of one problem with a second wave for
-//                       the cost side when few problems are left: line search 2^-k, k = 0..9 -- feedback
+//                       the cost side (and a third for the state regularisation) when few problems are left, all ten on three
+//                       workgroups for the problems flagged as needing them: line search 2^-k, k = 0..9 -- feedback
 //                       u = u - a k - K dx, node evaluation spread over the sub-group's lanes (legs, base, state
 //                       cost, control cost + Euler step); acceptance, regularisation update and stopping test
 //                       as crocoddyl 1.9.0 solver-ddp.cpp.
