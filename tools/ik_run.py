@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """two batch solves of KinoDynMP.optimize (the second is the one to look at in a kernel trace), printing the wall time.
-usage: tools/ik_run.py solo12_h20|go2_h60 [B] [spec_below] [all_steps_below]"""
+usage: tools/ik_run.py solo12_h20|go2_h60 [B] [spec_below] [all_steps_below] [gains_wave_below]"""
 import dataclasses, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,6 +15,8 @@ if len(sys.argv) > 3:
     lib.bmpc_ik_set_speculative_below(int(sys.argv[3]))
 if len(sys.argv) > 4:
     lib.bmpc_ik_set_all_steps(int(sys.argv[4]))
+if len(sys.argv) > 5:
+    lib.bmpc_ik_set_gains_wave_below(int(sys.argv[5]))
 robot = "go2" if cfg == "go2_h60" else "solo12"
 model = urdf_model.RobotModel.from_json(open(os.path.join(ROOT, "bunmpc_amd", "robots", robot + ".json")).read())
 if cfg == "go2_h60":
