@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """one warm-up + N timed batch solves of a bench workload, nothing else (the program rocprofv3's counter passes run).
-usage: tools/pmc_workload.py biconvex|solo12_h20|go2_h60 [N=2]"""
+usage: tools/pmc_workload.py biconvex|go2_bound_f32|go2_bound_f64|solo12_h20|go2_h60 [N=2]"""
 import dataclasses, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,6 +9,8 @@ from bunmpc_amd import batch as bb, problems, urdf_model
 what, N = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 2
 if what == "biconvex":
     job = bb.DeviceBatch(problems.make_batch("solo12_trot", 4096), num_iters=10).solve
+elif what.startswith("go2_bound"):      # BASELINE config 3's workload
+    job = bb.DeviceBatch(problems.make_batch("go2_bound", 4096), num_iters=10, precision="f32" if what.endswith("f32") else "f64").solve
 else:
     from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
     robot = "go2" if what == "go2_h60" else "solo12"
