@@ -24,6 +24,10 @@ import os
 import sys
 import time
 
+# the CPU-baseline legs run OpenMP regions (oracle/*.so); their worker threads must go to sleep afterwards instead of spinning on
+# the cores the host-driven DDP loop of the next GPU leg runs on (libgomp reads this when it is loaded)
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
