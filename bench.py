@@ -230,17 +230,18 @@ def ik_algorithmic_bytes(T, E=4):
 class Dist:
     """the rank bookkeeping every leg shares: barrier + synchronize brackets, MAX / SUM reductions of scalars"""
 
-    def __init__(self, torch, dist, dev, world, rank, rehearsal):
+    def __init__(self, torch, dist, dev, world, rank, rehearsal, group=False):
         self.torch, self.dist, self.dev, self.world, self.rank, self.rehearsal = torch, dist, dev, world, rank, rehearsal
+        self.group = group          # a process group is up (RCCL; gloo in the rehearsal): also at world size 1
 
     def sync(self):
-        if self.world > 1:
+        if self.group:
             self.dist.barrier()
         self.torch.cuda.synchronize(self.dev)
 
     def reduce(self, values, op):
         t = self.torch.tensor([float(v) for v in values], dtype=self.torch.float64, device="cpu" if self.rehearsal else self.dev)
-        if self.world > 1:
+        if self.group:
             self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
         return [float(v) for v in t]
 
@@ -293,14 +294,15 @@ def kinodyn_leg(D, B, admm_iters, maxit, config="solo12_h20", steps=3, warmup=1,
     # n_streams batches in flight on as many HIP streams, one host thread each (bunmpc_amd/pipeline.py): the tail
     # iterations of one batch -- a few stragglers, most of the chip idle -- overlap the bulk phases of the others.
     # Whole-job throughput of a generator that keeps several batches going.
-    from bunmpc_amd.pipeline import StreamPool
-    kbs = [kb] + [KinoDynDeviceBatch(wb, model, device=dev, num_iters=admm_iters, maxit=maxit) for _ in range(n_streams - 1)]
+    from bunmpc_amd.pipeline import IN_FLIGHT_SCHEDULE, StreamPool
+    kbs = [KinoDynDeviceBatch(wb, model, device=dev, num_iters=admm_iters, maxit=maxit, schedule=IN_FLIGHT_SCHEDULE if n_streams > 1 else None)
+           for _ in range(n_streams)]
     if n_streams not in _POOLS:    # one pool per run: HIP spreads streams over a few hardware queues, and new streams per
         _POOLS[n_streams] = StreamPool(dev, n_streams)       # leg can land on one queue and serialise
     pool = _POOLS[n_streams]
     dt2 = D.timed(lambda: pool.run([k.solve for k in kbs]), steps, 1) / steps
     same = True
-    for k in kbs[1:]:
+    for k in kbs:
         r2 = k.results()
         same = same and bool(np.array_equal(r2["xs"], r["xs"]) and np.array_equal(r2["ik_iters"], r["ik_iters"]))
     del kbs
@@ -465,6 +467,56 @@ def fp32_parity_note(pb, args):
             "same_admm_count": bool(np.array_equal(got["stats"][:, 0], ref["stats"][:, 0]))}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes the way the driver does
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...`), BEFORE this process has touched the GPU, pass
+    rank 0's JSON line through and exit with the launcher's code.  The library is built (if stale) here, once, so that the
+    ranks only load it."""
+    import subprocess
+    from bunmpc_amd import build as hip_build
+    if os.path.exists(hip_build.HIPCC):
+        hip_build.build()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), BUNMPC_BENCH_CHILD="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without WORLD_SIZE: launching %s" % (n, " ".join(cmd)), file=sys.stderr)
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
+def init_rccl_at_one(torch, dist, dev):
+    """World size 1 and no launcher: bring RCCL up anyway (one rank, TCP store on 127.0.0.1), so that the barriers and the
+    MAX / SUM reductions of every leg run through the same collectives as at N > 1 -- and a broken RCCL shows at N = 1.
+    Returns the record that goes into the line; a failure is recorded, never fatal (the N = 1 measurement does not need it)."""
+    if os.environ.get("BUNMPC_BENCH_NO_RCCL_AT_ONE") == "1":
+        return {"initialised": False, "note": "switched off (BUNMPC_BENCH_NO_RCCL_AT_ONE=1)"}
+    try:
+        import datetime
+        t0 = time.perf_counter()
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1, device_id=dev,
+                                timeout=datetime.timedelta(seconds=120))
+        t = torch.tensor([3.0, 5.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        ok = [float(v) for v in t] == [3.0, 5.0]
+        return {"initialised": bool(ok), "backend": "nccl (RCCL)", "world": 1, "init_seconds": time.perf_counter() - t0}
+    except Exception as e:       # noqa: BLE001 -- recorded in the line
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:        # noqa: BLE001
+            pass
+        return {"initialised": False, "error": "%s: %s" % (type(e).__name__, e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -490,6 +542,11 @@ def main():
                     help="f32: BASELINE config 3's mixed-precision kernel (fp32 iterates, fp64 decisions)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if os.environ.get("BUNMPC_BENCH_CHILD") == "1":
+            raise SystemExit("bench.py: launched as a rank but WORLD_SIZE is missing")
+        raise SystemExit(self_launch(args.gpus))
+
     # stdout carries the JSON line and nothing else: whatever the legs (or the C++ side of the drop-in classes) print goes to stderr
     sys.stdout.flush()
     json_fd = os.dup(1)
@@ -508,15 +565,19 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    rccl = None
+    if world > 1 or "WORLD_SIZE" in os.environ:      # under a launcher (torchrun sets WORLD_SIZE also for one rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        rccl = {"initialised": True, "backend": "gloo (one-device rehearsal)" if rehearsal else "nccl (RCCL)", "world": world}
+    else:
+        rccl = init_rccl_at_one(torch, dist, dev)
     if args.gpus != world and rank == 0:
         print("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
-    D = Dist(torch, dist, dev, world, rank, rehearsal)
+    D = Dist(torch, dist, dev, world, rank, rehearsal, group=dist.is_initialized())
     cpu_ok = world == 1 and not args.no_cpu
     if cpu_ok:
         build_oracles()
@@ -584,12 +645,13 @@ def main():
                                                                       cpu_sample=kd_sample("go2_h60")))
                 if world == 1:
                     out["datagen_pass"] = guarded(lambda: datagen_leg(dev, kd_batch(cfg), args.admm_iters))
+    out["rccl"] = rccl
     sys.stdout.flush()
     os.dup2(json_fd, 1)
     os.close(json_fd)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

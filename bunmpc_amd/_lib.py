@@ -140,6 +140,7 @@ _SIGS = {
     "bmpc_biconvex_solve_batch_device": (_I, [_P, _P]),
     "bmpc_biconvex_solve_batch_host": (_I, [_P]),
     "bmpc_biconvex_kernel_name": (C.c_char_p, [_I, _I]),
+    "bmpc_biconvex_last_kernel_name": (C.c_char_p, []),
     "bmpc_plan_batch_device": (_I, [_P, _P]),
     "bmpc_wb_plan_batch_device": (_I, [_P, _P]),
     "bmpc_interp_batch_device": (_I, [_P, _P]),
@@ -176,6 +177,7 @@ _SIGS = {
     "bmpc_ik_set_profile": (_I, [_I]),
     "bmpc_ik_set_all_steps": (_I, [_I]),
     "bmpc_ik_set_gains_wave_below": (_I, [_I]),
+    "bmpc_ik_set_blocking_waits": (_I, [_I]),
     "bmpc_ik_batch_struct_size": (_I, []),
     "bmpc_ik_active_list_ints": (C.c_long, [C.c_long]),
     "bmpc_ik_last_profile": (None, [_P]),
@@ -196,13 +198,18 @@ _SIGS = {
 IK_NODE_TASK_DOUBLES = 33
 
 
+class IkSched(C.Structure):
+    """bmpc_ik_sched_t: per-batch scheduling thresholds (0 = process default, < 0 = never)"""
+    _fields_ = [("spec_below", C.c_int), ("all_steps_below", C.c_int), ("gains_wave_below", C.c_int), ("debug_inject", C.c_int)]
+
+
 class IkBatch(C.Structure):
     """bmpc_ik_batch_t"""
     _fields_ = ([("B", C.c_int), ("n_col", C.c_int), ("maxiter", C.c_int), ("model", C.c_void_p)] +
                 [(n, C.c_void_p) for n in ("x0", "dt", "tasks", "state_w", "x_reg", "ctrl_w")] +
                 [("s_state_w", C.c_long), ("s_ctrl_w", C.c_long), ("ws", C.c_void_p), ("active", C.c_void_p),
                  ("iters_run", C.c_void_p), ("s_x_reg", C.c_long), ("sn_state_w", C.c_long), ("sn_x_reg", C.c_long),
-                 ("sn_ctrl_w", C.c_long), ("active_list", C.c_void_p)])
+                 ("sn_ctrl_w", C.c_long), ("active_list", C.c_void_p), ("sched", IkSched)])
 
 
 class KinoDynBatch(C.Structure):

@@ -7,6 +7,8 @@ csrc/_obj, keyed by the flags) and linked, so touching one kernel file recompile
     python -m bunmpc_amd.build [--force] [--usage]
 Environment: HIPCC, BUNMPC_EXTRA_FLAGS (extra compile flags, e.g. -DBWD_PROFILE), BUNMPC_LIB_OUT
 (output path, for side-by-side experiment builds; load it with BUNMPC_LIB=<path>)."""
+import contextlib
+import fcntl
 import hashlib
 import os
 import subprocess
@@ -34,10 +36,30 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+@contextlib.contextmanager
+def build_lock():
+    """One builder at a time per tree (the ranks of a multi-GPU job start together and share csrc/_obj and the .so): the
+    first to arrive builds, the others wait here and then find the library fresh."""
+    os.makedirs(OBJ, exist_ok=True)
+    with open(os.path.join(OBJ, ".build.lock"), "w") as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(f, fcntl.LOCK_UN)
+
+
 def build(force=False, verbose=False, extra_flags=()):
     out = os.environ.get("BUNMPC_LIB_OUT", LIB)
     if not force and out == LIB and not is_stale():
         return LIB
+    with build_lock():
+        if not force and out == LIB and not is_stale():      # another process built it while this one waited
+            return LIB
+        return _build_locked(out, force, verbose, extra_flags)
+
+
+def _build_locked(out, force, verbose, extra_flags):
     if not os.path.exists(HIPCC):
         raise RuntimeError("hipcc not found at %s: cannot build %s" % (HIPCC, out))
     flags = FLAGS + os.environ.get("BUNMPC_EXTRA_FLAGS", "").split() + list(extra_flags)
@@ -57,10 +79,12 @@ def build(force=False, verbose=False, extra_flags=()):
     for cmd, p in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+    tmp = "%s.tmp.%d" % (out, os.getpid())     # linked beside, then renamed: a process loading the library never sees half of it
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    os.replace(tmp, out)
     return out
 
 

@@ -68,5 +68,7 @@ hipError_t launch_lane_selftest(const double *in, double *out, hipStream_t strea
 
 // Name of the kernel symbol for a given H (for profiling / bench reports).
 const char *biconvex_kernel_name(int H, int raw);
+// ... and of the kernel the calling host thread's latest launch_biconvex_admm actually took
+const char *biconvex_last_kernel_name();
 
 }  // namespace bunmpc

@@ -649,5 +649,6 @@ int bmpc_biconvex_solve_batch_host(const bmpc_batch_t *d) {
 }
 
 const char *bmpc_biconvex_kernel_name(int n_col, int raw) { return bunmpc::biconvex_kernel_name(n_col, raw); }
+const char *bmpc_biconvex_last_kernel_name(void) { return bunmpc::biconvex_last_kernel_name(); }
 
 }  // extern "C"

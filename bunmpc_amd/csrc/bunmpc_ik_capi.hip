@@ -10,6 +10,7 @@ namespace bunmpc {
 int launch_wb_plan(const RobotModelDev *model, const bmpc_wb_plan_batch_t &d, hipStream_t st);   // plan_gen.hip
 }
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -148,20 +149,29 @@ bunmpc::IkBatchArgs make_args(int B, int T, int maxiter, const bmpc_model *model
     a.x0 = x0; a.dt = dt; a.tasks = tasks; a.state_w = state_w; a.x_reg = x_reg; a.ctrl_w = ctrl_w;
     a.s_state_w = s_sw; a.s_ctrl_w = s_cw; a.ws = ws; a.active = active;
     a.s_x_reg = bunmpc::kNX; a.sn_state_w = a.sn_x_reg = a.sn_ctrl_w = 0; a.fwd_spec = 0; a.bwd_waves = 1;
-    a.list = nullptr; a.count = nullptr; a.wide = nullptr; a.wcount = nullptr; a.iter = 0; a.n_launch = B;
+    a.list = nullptr; a.count = nullptr; a.wide = nullptr; a.wcount = nullptr; a.err = nullptr; a.iter = 0; a.n_launch = B;
     return a;
 }
 
 // the DDP iteration loop (SolverDDP::solve): three launches per iteration, stop when every problem is done
 // below this many active problems the forward pass runs four step lengths of a problem side by side (one wave per
 // problem: 1024 SIMDs on an MI355X)
-int g_spec_line_search_below = 1024;
-int g_all_steps = 0;              // at most this many active problems: all ten step lengths at once, three workgroups per problem
+// Process-wide DEFAULTS of the scheduling thresholds (the bmpc_ik_set_* entry points); a batch may carry its own in
+// bmpc_ik_batch_t.sched.  A DDP loop reads them once, when it starts: a setter called meanwhile (another host thread) changes
+// the next loop, never one that is running.
+std::atomic<int> g_spec_line_search_below{1024};
+std::atomic<int> g_all_steps{0};  // at most this many active problems: all ten step lengths at once, three workgroups per problem
                                   // (0 = never, the default: measured on the MI355X it gains < 1 % on the Go2 H = 60 batch at <= 85 -- one workgroup of
                                   // three waves per CU is the forward kernel's residency -- and loses 2 % on Solo12)
-int g_gains_wave_below = 512;     // at most this many active problems: the backward pass gives each a second wave for the gains
+std::atomic<int> g_gains_wave_below{512};   // at most this many active problems: the backward pass gives each a second wave for the gains
                                   // (two waves per problem on the MI355X's 1024 SIMDs; no effect on results)
+std::atomic<int> g_blocking_waits{1};       // the DDP loop's host waits sleep on an interrupt (hipEventBlockingSync) instead of spinning
 constexpr int kMaxIkCol = 63;     // T + 1 <= 64 nodes: the backward pass computes the gaps one lane per node
+
+// thresholds of ONE DDP loop: field of bmpc_ik_batch_t.sched (0 = the process default, < 0 = never, n > 0 = n)
+struct Sched { int spec_below, all_steps, gains_wave_below; int debug_inject = 0; };
+int sched_pick(int field, const std::atomic<int> &dflt) { return field == 0 ? dflt.load() : field < 0 ? 0 : field; }
+Sched default_sched() { return Sched{g_spec_line_search_below.load(), g_all_steps.load(), g_gains_wave_below.load()}; }
 
 // Two host-mapped words and events per (device, stream), through which the kernels' active counter reaches the DDP loop.
 // Keyed by the stream, not by the host thread: a stream's publishes are ordered among themselves, so a late publish of one
@@ -169,14 +179,17 @@ constexpr int kMaxIkCol = 63;     // T + 1 <= 64 nodes: the backward pass comput
 // ever used) live as long as the library, whatever threads come and go (bunmpc_amd/pipeline.py starts workers per call).
 struct ActiveWord {
     int *host[2] = {nullptr, nullptr}, *dev[2] = {nullptr, nullptr};
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    // evs[0]: spinning waits, evs[1]: blocking waits (hipEventBlockingSync: the waiting host thread sleeps until the interrupt --
+    // with eight ranks of up to three pool threads each on a 16-core cgroup, spinning waits would fight the other ranks' loops)
+    hipEvent_t evs[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     std::mutex in_use;      // one DDP loop at a time per stream (two host threads driving one stream would interleave anyway)
     int ensure() {
         if (host[0]) return BMPC_OK;
         for (int k = 0; k < 2; ++k) {
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&host[k]), sizeof(int), hipHostMallocMapped));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&host[k]), 2 * sizeof(int), hipHostMallocMapped));   // [active, index-check code]
             HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&dev[k]), host[k], 0));
-            HIP_TRY(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&evs[0][k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&evs[1][k], hipEventDisableTiming | hipEventBlockingSync));
         }
         return BMPC_OK;
     }
@@ -201,7 +214,7 @@ bool g_profile = false;
 double g_last_profile[5] = {0, 0, 0, 0, 0};     // ms: state, calcdiff, backward, forward, everything else in the loop
 std::mutex g_profile_lock;
 
-int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run) {
+int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run, const Sched sched) {
     bunmpc::IkBatchArgs a = a0;
     a.fwd_spec = 0;
     const bool prof = g_profile;
@@ -219,7 +232,9 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run) {
     ActiveWord &w = *wp;
     std::lock_guard<std::mutex> hold(w.in_use);
     if (int rc = w.ensure()) return rc;
+    hipEvent_t *ev = w.evs[g_blocking_waits.load() ? 1 : 0];
     HIP_TRY(bunmpc::ik_launch_init(a, st));
+    if (sched.debug_inject == 1 && a.list) HIP_TRY(hipMemsetAsync(a.list, 0x7f, sizeof(int), st));      // tests: an entry far out of range
     // The host looks at the active counter after every iteration while many problems are iterating (iterations are long
     // there and the line-search mapping depends on it); once few are left it enqueues kTailChunk iterations per look --
     // kernels of a finished problem return at once, so an iteration too many costs a few microseconds.  And it looks
@@ -228,9 +243,9 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run) {
     constexpr int kTailChunk = 3;
     int active = a.B, it = 0, it_end[2] = {0, 0};
     auto enqueue_chunk = [&](int slot) -> int {
-        const int chunk = active <= g_spec_line_search_below ? kTailChunk : 1;
-        a.fwd_spec = active <= g_all_steps ? 4 : active <= g_spec_line_search_below / 3 ? 3 : active <= g_spec_line_search_below ? 2 : 0;
-        a.bwd_waves = active <= g_gains_wave_below ? 2 : 1;
+        const int chunk = active <= sched.spec_below ? kTailChunk : 1;
+        a.fwd_spec = active <= sched.all_steps ? 4 : active <= sched.spec_below / 3 ? 3 : active <= sched.spec_below ? 2 : 0;
+        a.bwd_waves = active <= sched.gains_wave_below ? 2 : 1;
         a.n_launch = active;        // the host's latest look at the counter: an upper bound of the active list's length
         for (int k = 0; k < chunk && it < a.maxiter; ++k, ++it) {
             a.iter = it;
@@ -244,30 +259,38 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run) {
             HIP_TRY(bunmpc::ik_launch_forward(a, st));
             if (int rc = stamp()) return rc;
         }
-        HIP_TRY(bunmpc::ik_launch_publish_active(a.active, w.dev[slot], st));
-        HIP_TRY(hipEventRecord(w.ev[slot], st));
+        HIP_TRY(bunmpc::ik_launch_publish_active(a.active, a.err, w.dev[slot], st));
+        HIP_TRY(hipEventRecord(ev[slot], st));
         it_end[slot] = it;
         return BMPC_OK;
     };
-    int slot = 0, it_done = 0;
+    int slot = 0, it_done = 0, index_err = 0;
     if (a.maxiter > 0 && active > 0) {
         if (int rc = enqueue_chunk(slot)) return rc;
         for (;;) {
             const bool more = it < a.maxiter;
             if (more) { if (int rc = enqueue_chunk(slot ^ 1)) return rc; }
-            HIP_TRY(hipEventSynchronize(w.ev[slot]));
-            active = *static_cast<volatile int *>(w.host[slot]);
+            HIP_TRY(hipEventSynchronize(ev[slot]));
+            active = static_cast<volatile int *>(w.host[slot])[0];
+            index_err = static_cast<volatile int *>(w.host[slot])[1];
             it_done = it_end[slot];
+            if (index_err) active = 0;       // an index of the list code was out of range: stop, report below
             if (active <= 0 || !more) {
                 // the chunk enqueued ahead (no-op kernels and one more publish into the other word) must have drained before
                 // this stream's words can serve another batch
-                if (more) HIP_TRY(hipEventSynchronize(w.ev[slot ^ 1]));
+                if (more) HIP_TRY(hipEventSynchronize(ev[slot ^ 1]));
                 break;
             }
             slot ^= 1;
         }
     }
     if (iters_run) *iters_run = it_done;     // iterations up to the look that found every problem done (not the chunk enqueued ahead)
+    if (index_err) {
+        static const char *what[] = {"", "active-list entry out of range", "active-list length out of range", "active-list append past its end",
+                                     "wide-list entry out of range"};
+        return ik_fail(BMPC_DEVICE_ERROR, std::string("IK-DDP index check failed: ") + what[index_err < 5 ? index_err : 0] +
+                       " (code " + std::to_string(index_err) + "); results of this batch are invalid");
+    }
     if (prof && !pev.empty()) {
         HIP_TRY(hipEventSynchronize(pev.back()));
         double acc[5] = {0, 0, 0, 0, 0};
@@ -433,9 +456,10 @@ int bmpc_ik_selftest_state_ops(const double *x0, const double *x1, const double 
     HIP_TRY(hipMemcpy(ir, out.d() + 2 * nd + nx, sizeof(double) * nx, hipMemcpyDeviceToHost));
     return BMPC_OK;
 }
-int bmpc_ik_set_all_steps(int n_active) { const int old = g_all_steps; g_all_steps = n_active; return old; }
+int bmpc_ik_set_all_steps(int n_active) { return g_all_steps.exchange(n_active); }
+int bmpc_ik_set_blocking_waits(int on) { return g_blocking_waits.exchange(on != 0); }
 int bmpc_ik_batch_struct_size(void) { return (int)sizeof(bmpc_ik_batch_t); }
-int bmpc_ik_set_speculative_below(int n_active) { const int old = g_spec_line_search_below; g_spec_line_search_below = n_active; return old; }
+int bmpc_ik_set_speculative_below(int n_active) { return g_spec_line_search_below.exchange(n_active); }
 double bmpc_model_total_mass(const bmpc_model_t *m) { return m ? m->host.total_mass : 0.0; }
 
 // ----------------------------------------------------------- InverseKinematics ----
@@ -585,7 +609,7 @@ int bmpc_ik_optimize(bmpc_ik_t *h, const double *x0) {
     IkBatchArgs a = make_args(1, T, 100, model, d + o_x0, d + o_dt, d + o_tk, d + o_sw, 0, d + o_xr, d + o_cw, 0, h->dws.d(),
                               static_cast<int *>(h->dactive.p));
     a.sn_state_w = kNDX; a.sn_x_reg = kNX; a.sn_ctrl_w = kNV;
-    if (int rc = run_ddp(a, nullptr, nullptr)) return rc;
+    if (int rc = run_ddp(a, nullptr, nullptr, default_sched())) return rc;
     h->xs.resize((size_t)nn * kNX); h->us.resize((size_t)T * kNV);
     double scal[16];
     HIP_TRY(hipMemcpy(h->xs.data(), h->dws.d() + L.xs, sizeof(double) * h->xs.size(), hipMemcpyDeviceToHost));
@@ -646,9 +670,11 @@ int bmpc_ik_solve_batch_device(const bmpc_ik_batch_t *d, void *hip_stream) {
                               d->ctrl_w, d->s_ctrl_w, d->ws, d->active);
     a.s_x_reg = d->s_x_reg ? d->s_x_reg : kNX;
     a.sn_state_w = d->sn_state_w; a.sn_x_reg = d->sn_x_reg; a.sn_ctrl_w = d->sn_ctrl_w;
-    if (d->active_list) { a.list = d->active_list; a.count = a.list + 2 * (long)d->B; a.wcount = a.count + 2; a.wide = a.wcount + 2; }
+    if (d->active_list) { a.list = d->active_list; a.count = a.list + 2 * (long)d->B; a.wcount = a.count + 2; a.wide = a.wcount + 2; a.err = a.wide + 2 * kWideMax; }
     int iters = 0;
-    int rc = run_ddp(a, static_cast<hipStream_t>(hip_stream), &iters);
+    const Sched sched{sched_pick(d->sched.spec_below, g_spec_line_search_below), sched_pick(d->sched.all_steps_below, g_all_steps),
+                      sched_pick(d->sched.gains_wave_below, g_gains_wave_below), d->sched.debug_inject};
+    int rc = run_ddp(a, static_cast<hipStream_t>(hip_stream), &iters, sched);
     if (d->iters_run) *d->iters_run = iters;
     return rc;
 }
@@ -665,7 +691,7 @@ void bmpc_ik_layout(int n_col, long *offsets8) {   // xs, us, scal, K, kff, fs, 
     offsets8[5] = L.fs; offsets8[6] = L.Lx; offsets8[7] = L.Lxx;
 }
 
-int bmpc_ik_set_gains_wave_below(int n_active) { const int old = g_gains_wave_below; g_gains_wave_below = n_active; return old; }
+int bmpc_ik_set_gains_wave_below(int n_active) { return g_gains_wave_below.exchange(n_active); }
 long bmpc_ik_active_list_ints(long B) { return bunmpc::active_list_ints(B); }
 
 void bmpc_ik_layout_trace(int n_col, long *offset, int *iters, int *width) {   // the per-iteration telemetry rows of a problem's workspace

@@ -120,11 +120,19 @@ __device__ __forceinline__ double node_cost(const RobotModelDev &m, const double
 
 __device__ const double *batch_ptr(const double *p, long stride, long b) { return p + stride * b; }
 
+// index checks of the list code (ik_types.h::IkIndexError): the first failure is recorded, the access dropped
+__device__ __forceinline__ void index_error(const IkBatchArgs &a, int code, int value) {
+    if (a.err && atomicCAS(a.err, 0, code) == 0) a.err[1] = value;
+}
 // problem handled by launch slot `slot` of this DDP iteration: through the active list when there is one (-1: past its end)
 __device__ __forceinline__ long slot_problem(const IkBatchArgs &a, long slot) {
     if (!a.list) return slot < a.B ? slot : -1;
-    const int cur = a.iter & 1;
-    return slot < a.count[cur] ? (long)a.list[(long)cur * a.B + slot] : -1;
+    const int cur = a.iter & 1, n = a.count[cur];
+    if ((unsigned)n > (unsigned)a.B) { index_error(a, IK_ERR_LIST_COUNT, n); return -1; }
+    if (slot >= n) return -1;
+    const int p = a.list[(long)cur * a.B + slot];
+    if ((unsigned)p >= (unsigned)a.B) { index_error(a, IK_ERR_LIST_ENTRY, p); return -1; }
+    return p;
 }
 
 // ------------------------------------------------------------------------------- init ---
@@ -146,7 +154,7 @@ __global__ void ik_init_kernel(const IkBatchArgs a) {
     s[S_DONE] = 0; s[S_ITERS] = 0; s[S_RECALC] = 1; s[S_STATUS] = 0; s[S_WIDE] = 0; s[S_WIDENOW] = 0;
     ws[L.arrive] = 0.0;          // (read as an unsigned counter)
     if (a.list) a.list[b] = (int)b;
-    if (b == 0) { *a.active = a.B; if (a.count) { a.count[0] = a.B; a.count[1] = 0; a.wcount[0] = 0; a.wcount[1] = 0; } }
+    if (b == 0) { *a.active = a.B; if (a.count) { a.count[0] = a.B; a.count[1] = 0; a.wcount[0] = 0; a.wcount[1] = 0; a.err[0] = 0; a.err[1] = 0; } }
 }
 
 // --------------------------------------------------------------------------- calcDiff ---
@@ -995,6 +1003,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
     if (extra) {
         const int e = (int)(blockIdx.x >> 1), cur = a.iter & 1, nw = a.wcount[cur] < kWideMax ? a.wcount[cur] : kWideMax;
         b = e < nw ? (long)a.wide[cur * kWideMax + e] : -1;
+        if (b >= a.B || b < -1) { index_error(a, IK_ERR_WIDE_ENTRY, (int)b); b = -1; }
         grp = 1 + (int)(blockIdx.x & 1);
     } else b = slot_problem(a, all10_batch ? blk / 3 : spec ? blk : blk * kFwdSub + si);
     const bool pvalid = b >= 0;
@@ -1304,7 +1313,9 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
         sc[S_XREG] = xreg; sc[S_ITERS] = iters;
         if (!done && a.list) {      // goes on: onto the next iteration's list (the order there is arbitrary; nothing depends on it)
             const int nxt = (a.iter + 1) & 1;
-            a.list[(long)nxt * a.B + atomicAdd(a.count + nxt, 1)] = (int)b;
+            const int pos = atomicAdd(a.count + nxt, 1);
+            if ((unsigned)pos < (unsigned)a.B) a.list[(long)nxt * a.B + pos] = (int)b;
+            else index_error(a, IK_ERR_LIST_APPEND, pos);
             if (widen) sc[S_WIDE] = 1.0;
             double now = 0.0;
             if (a.wide && (widen || sc[S_WIDE] != 0.0)) {     // a place on the wide list while there are any
@@ -1365,8 +1376,9 @@ __global__ void ik_state_ops_selftest_kernel(const double *x0, const double *x1,
 
 // the active-problem counter, copied to a host-mapped word: the host reads it after its stream synchronisation
 // without a device-to-host copy operation (a 4-byte hipMemcpy into pageable memory costs ~50 us per DDP iteration)
-__global__ void ik_publish_active_kernel(const int *active, volatile int *host_word) {
-    *host_word = *active;
+__global__ void ik_publish_active_kernel(const int *active, const int *err, volatile int *host_word) {
+    host_word[1] = err ? err[0] : 0;
+    host_word[0] = *active;
     __threadfence_system();
 }
 
@@ -1398,8 +1410,8 @@ hipError_t ik_launch_state_ops_selftest(const double *x0, const double *x1, cons
     hipLaunchKernelGGL(ik_state_ops_selftest_kernel, dim3((n + 63) / 64), dim3(64), 0, st, x0, x1, dx, n, dq, dr, iq, ir);
     return hipGetLastError();
 }
-hipError_t ik_launch_publish_active(const int *active, int *host_word_dev, hipStream_t st) {
-    hipLaunchKernelGGL(ik_publish_active_kernel, dim3(1), dim3(1), 0, st, active, host_word_dev);
+hipError_t ik_launch_publish_active(const int *active, const int *err, int *host_word_dev, hipStream_t st) {
+    hipLaunchKernelGGL(ik_publish_active_kernel, dim3(1), dim3(1), 0, st, active, err, host_word_dev);
     return hipGetLastError();
 }
 hipError_t ik_launch_init(const IkBatchArgs &a, hipStream_t st) {

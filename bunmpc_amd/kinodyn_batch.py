@@ -11,9 +11,10 @@ from .inverse_kinematics_cpp import as_device_model
 
 
 class KinoDynDeviceBatch:
-    def __init__(self, wb, model, device="cuda", num_iters=10, maxit=150, ddp_maxiter=100, plan=None, use_active_list=True):
+    def __init__(self, wb, model, device="cuda", num_iters=10, maxit=150, ddp_maxiter=100, plan=None, use_active_list=True, schedule=None):
         """plan: a plan_batch.DeviceWbPlan whose tensors replace the host-built centroidal inputs and IK task blocks of
-        `wb` (weights and regularisation references still come from wb)"""
+        `wb` (weights and regularisation references still come from wb).  schedule: dict of bmpc_ik_sched_t fields for this
+        batch's DDP loops (0 = process default, < 0 = never), e.g. {"gains_wave_below": -1}; no effect on results"""
         import torch
         self.torch = torch
         self.wb = wb
@@ -55,6 +56,14 @@ class KinoDynDeviceBatch:
         ik.iters_run = C.addressof(self.iters_run)
         d.x = self.x.data_ptr()
         self.desc = d
+        self.set_schedule(**(schedule or {}))
+
+    def set_schedule(self, **fields):
+        """per-batch scheduling thresholds of the DDP loop (bmpc_ik_sched_t)"""
+        for k, v in fields.items():
+            if k not in ("spec_below", "all_steps_below", "gains_wave_below", "debug_inject"):
+                raise KeyError(k)
+            setattr(self.desc.ik.sched, k, int(v))
 
     def carry_step_constants(self, on=True):
         """True: the next solves are further optimize calls of the SAME KinoDynMP objects (successive replans of the same

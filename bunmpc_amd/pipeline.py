@@ -10,6 +10,10 @@ streams onto 4 hardware queues, one of which the default stream holds)."""
 import threading
 
 DEFAULT_STREAMS = 3
+# The batched DDP gives every problem a second wave for the Riccati gains once few problems are left: that shortens ONE
+# batch's tail by using SIMDs that idle -- with several batches in flight they do not idle, the other batches use them
+# (measured, Go2 H = 60, three batches: 2.02e4 solves/s without, 1.97e4 at a third of the threshold, 1.90e4 with).
+IN_FLIGHT_SCHEDULE = {"gains_wave_below": -1}
 
 
 class StreamPool:
@@ -39,21 +43,12 @@ class StreamPool:
         cur = torch.cuda.current_stream(self.device)
         for s in self.streams:
             s.wait_stream(cur)               # inputs prepared on the caller's stream are visible to the jobs
-        # the batched DDP gives every problem a second wave for the Riccati gains once few problems are left: that shortens one
-        # batch's tail by using SIMDs that idle -- with several batches in flight they do not idle, the other batches use them
-        # (measured, Go2 H = 60, three batches: 2.02e4 solves/s without, 1.97e4 at a third of the threshold, 1.90e4 with)
-        from . import _lib
-        lib = _lib.lib()
-        old = lib.bmpc_ik_set_gains_wave_below(0)
-        if len(threads) < 2:
-            lib.bmpc_ik_set_gains_wave_below(old)
-        try:
-            for t in threads:
-                t.start()
-            for t in threads:
-                t.join()
-        finally:
-            lib.bmpc_ik_set_gains_wave_below(old)
+        # (Scheduling of the jobs' DDP loops is the jobs' own: batches meant to run several at a time are created with
+        # schedule=IN_FLIGHT_SCHEDULE -- a per-batch field of bmpc_ik_batch_t, not a process-wide switch flipped around the run.)
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
         for s in self.streams:
             cur.wait_stream(s)
         if errors:

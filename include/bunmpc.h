@@ -151,6 +151,9 @@ int bmpc_biconvex_solve_batch_host(const bmpc_batch_t *d);
 int bmpc_set_latency_mapping_max_batch(int max_batch);
 /* symbol-name prefix of the kernel that serves (n_col, raw), for profiles */
 const char *bmpc_biconvex_kernel_name(int n_col, int raw);
+/* which kernel the calling host thread's latest batch solve was dispatched to: "biconvex_latency_kernel" (one problem per wave),
+ * "biconvex_admm_kernel" or "biconvex_admm_kernel_f32" (one knot per lane); "" before the first solve */
+const char *bmpc_biconvex_last_kernel_name(void);
 
 /* rigid-body model -------------------------------------------------------------------
  * What pinocchio::urdf::buildModel(urdf, JointModelFreeFlyer()) yields (inverse_kinematics.cpp:10,
@@ -210,6 +213,16 @@ int bmpc_ik_last_stats(const bmpc_ik_t *h, int *iters, int *status, double *cost
  *       (what the acyclic generator's time-varying add_*_regularization_cost_single calls produce)
  *   ws [B][bmpc_ik_workspace_doubles(n_col)] scratch + results (offsets: bmpc_ik_layout), active: one int */
 #define BMPC_IK_NODE_TASK_DOUBLES 33
+/* Scheduling thresholds of ONE batch solve (no effect on results; they replace flipping the process-wide bmpc_ik_set_* defaults
+ * around a call, which raced between host threads driving different streams).  Every field: 0 = the process default,
+ * < 0 = never, n > 0 = while at most n problems are still iterating. */
+typedef struct {
+    int spec_below;         /* four step lengths of a problem side by side (bmpc_ik_set_speculative_below) */
+    int all_steps_below;    /* all ten step lengths at once on three workgroups (bmpc_ik_set_all_steps) */
+    int gains_wave_below;   /* a second wave per problem for the Riccati gains (bmpc_ik_set_gains_wave_below) */
+    int debug_inject;       /* tests only: 1 = overwrite the first active-list entry with an out-of-range index right after the
+                               list is initialised; the solve must then return BMPC_DEVICE_ERROR (index checks of the list code) */
+} bmpc_ik_sched_t;
 typedef struct {
     int B, n_col, maxiter;
     const bmpc_model_t *model;
@@ -223,6 +236,7 @@ typedef struct {
                          only the problems still iterating (an index list the forward pass rebuilds each iteration), and the few
                          problems whose line search goes past four step lengths get all ten at once from then on; without it
                          every launch covers all B and finished problems return at once.  Results do not depend on it. */
+    bmpc_ik_sched_t sched;
 } bmpc_ik_batch_t;
 int bmpc_ik_batch_struct_size(void);     /* sizeof(bmpc_ik_batch_t), to catch binding drift */
 long bmpc_ik_active_list_ints(long B);   /* length of bmpc_ik_batch_t.active_list */
@@ -241,6 +255,9 @@ int bmpc_ik_set_all_steps(int n_active);
 /* Riccati-pass scheduling (no effect on results): while at most n_active problems are still iterating, each gets a second
  * wave that computes and stores the gains K, k one node behind the recursion.  Default 512; 0 = never.  Returns the old value. */
 int bmpc_ik_set_gains_wave_below(int n_active);
+/* Host waits of the DDP loop (no effect on results): 1 (default) = the waiting host thread sleeps until the device's interrupt
+ * (hipEventBlockingSync), 0 = it spins.  Returns the old value. */
+int bmpc_ik_set_blocking_waits(int on);
 int bmpc_ik_solve_batch_device(const bmpc_ik_batch_t *d, void *hip_stream);
 /* Measurement aid (additive): with profiling on, the DDP loop brackets each of its kernels with events; after a batch solve
  * bmpc_ik_last_profile returns the summed milliseconds of ik_state / ik_calcdiff / ik_backward / ik_forward and of the rest

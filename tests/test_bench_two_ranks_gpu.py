@@ -75,6 +75,38 @@ def test_two_rank_bench_shards_every_leg():
     assert out["kinodyn_go2_h60"]["ddp_iters_mean"] == pytest.approx(r["ik_iters"].mean(), rel=1e-12)
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts the two ranks itself (torch.distributed.run,
+    before it touches the GPU) and passes rank 0's line through.  Both ranks on cuda:0 over gloo here (one-GPU box)."""
+    env = dict(os.environ, BUNMPC_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64",
+                        "--no-kinodyn"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 128 and out["value"] > 0
+    assert out["rccl"]["initialised"] and out["rccl"]["world"] == 2
+
+
+def test_rccl_runs_at_world_size_one():
+    """A plain `python bench.py` (N = 1, no launcher) brings RCCL up with one rank on the real device and sends every leg's
+    barrier and MAX / SUM reductions through it: the collectives of the N > 1 path have executed on this code."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BUNMPC_BENCH_ONE_DEVICE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "256", "--no-cpu",
+                        "--no-latency", "--kinodyn-batch", "64", "--kinodyn-steps", "1", "--kinodyn-main-only"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert out["rccl"]["initialised"], out["rccl"]
+    assert out["rccl"]["backend"].startswith("nccl") and out["rccl"]["world"] == 1
+    assert out["n_gpus"] == 1 and out["value"] > 0 and "error" not in out["kinodyn_full_solve"]
+
+
 def test_kinodyn_workload_line_single_rank():
     """`--workload kinodyn`: the full KinoDynMP.optimize as the measured line, with its own roofline and cpu_baseline"""
     env = dict(os.environ)

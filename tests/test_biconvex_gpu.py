@@ -78,7 +78,8 @@ def test_hundred_admm_iterations(oracle):
     print("100 iters: GPU-C rel err", err, "CPU spread", spread, "same discrete path:", same)
 
 
-GOLDEN = sorted(__import__("glob").glob(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(p for p in __import__("glob").glob(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "*.npz"))
+                if not __import__("os").path.basename(p).startswith("ik_"))       # ik_*: whole-body fixtures (tests/test_ik_gpu.py)
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[__import__("os").path.basename(p)[:-4] for p in GOLDEN])

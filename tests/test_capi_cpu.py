@@ -124,3 +124,17 @@ def test_batch_descriptor_validation():
     d.n_col = 64
     assert _lib.lib().bmpc_biconvex_solve_batch_host(C.byref(d)) == _lib.BAD_ARG
     assert b"64" in _lib.lib().bmpc_last_error()
+
+
+def test_build_lock_serialises_builders(tmp_path):
+    """the ranks of a multi-GPU job start together: whoever holds bunmpc_amd.build.build_lock() builds, the others wait"""
+    import subprocess
+    import sys
+    code = ("import sys, time; sys.path.insert(0, %r); from bunmpc_amd import build\n"
+            "with build.build_lock():\n"
+            "    t0 = time.time(); time.sleep(0.5); print(t0, time.time())\n") % ROOT
+    ps = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True) for _ in range(3)]
+    spans = sorted(tuple(float(v) for v in p.communicate()[0].split()) for p in ps)
+    assert all(p.returncode == 0 for p in ps) and len(spans) == 3
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert b0 >= a1 - 1e-3           # no two holders at a time

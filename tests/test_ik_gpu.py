@@ -343,3 +343,60 @@ def test_ik_longest_horizon(model):
     assert rel_l2(np.array(ik.get_xs()).reshape(-1), np.array(ref["xs"]).reshape(-1)) < 1e-8
     with pytest.raises(Exception):
         InverseKinematics(model, 64)
+
+
+IK_GOLDEN = sorted(__import__("glob").glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ik_*.npz")))
+
+
+@pytest.mark.parametrize("path", IK_GOLDEN, ids=[os.path.basename(p)[:-4] for p in IK_GOLDEN])
+def test_ik_golden_fixtures(path):
+    """Committed inputs / outputs of the whole-body DDP (tests/golden/make_golden_ik.py: four Solo12 problems, three synthetic-Go2
+    H = 60 / H_ik = 30 problems of which one runs to SolverDDP's maxiter), fed to bmpc_ik_solve_batch_device as the arrays the
+    file holds -- no oracle build, no problem generator between the fixture and the kernels.  The GPU must take the committed
+    discrete path (iteration count, status, every accepted step length and regularisation value) to the committed
+    trajectories.  PARITY UNPINNED (the fixtures are the CPU twin's outputs, not the reference's)."""
+    from tests.golden import make_golden_ik as mg
+    from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
+    import torch
+    g = np.load(path)
+    B = g["x0"].shape[0]
+    model, wb = mg.wb_batch(str(g["robot"]), B)
+    assert wb.ik_T == int(g["T"]) and wb.dyn.H == int(g["H"])
+    kb = KinoDynDeviceBatch(wb, model, num_iters=10)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(kb.device)      # noqa: E731
+    for dst, k in ((kb.x, "x0"), (kb.dt_ik, "dt"), (kb.tasks, "tasks"), (kb.state_w, "state_w"), (kb.x_reg, "x_reg"), (kb.ctrl_w, "ctrl_w")):
+        assert tuple(dst.shape) == g[k].shape, k
+        dst.copy_(up(g[k]))
+    kb.solve_ik_only()
+    r = kb.results()
+    assert np.array_equal(r["ik_iters"], g["iters"]) and np.array_equal(r["ik_status"], g["status"])
+    for i in range(B):
+        n = int(g["iters"][i])
+        assert np.array_equal(r["ik_trace"][i, :n, 1:3], g["trace"][i, :n, 1:3]), i
+        assert np.all(np.abs(r["ik_trace"][i, :n, 0] - g["trace"][i, :n, 0]) <= 1e-6 * np.abs(g["trace"][i, :n, 0])), i
+    assert np.all(np.abs(r["ik_cost"] - g["cost"]) <= 1e-8 * np.abs(g["cost"]))
+    e = rel_l2(r["xs"].reshape(B, -1), g["xs"].reshape(B, -1))
+    eu = rel_l2(r["us"].reshape(B, -1), g["us"].reshape(B, -1))
+    print("%s: xs rel-L2 vs fixture max %.2e, us max %.2e, iterations %s" % (os.path.basename(path), e.max(), eu.max(), r["ik_iters"].tolist()))
+    assert np.all(e < 1e-6) and np.all(eu < 1e-4)
+
+
+def test_list_index_checks_report_instead_of_faulting(model):
+    """An out-of-range entry in the active-problem list (injected through bmpc_ik_sched_t.debug_inject) is never used as an
+    index: the solve returns BMPC_DEVICE_ERROR naming the check, the process lives, and the next solve of the same objects is
+    clean.  (Round 2 lost a test run to an abort inside this code while it was being written; the checks are what would
+    have turned that into an error message.)"""
+    from bunmpc_amd import _lib
+    from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
+    wb = problems.make_wb_batch(model, 8)
+    kb = KinoDynDeviceBatch(wb, model, num_iters=10)
+    kb.solve()
+    good = kb.results()
+    kb.set_schedule(debug_inject=1)
+    with pytest.raises(_lib.BmpcError) as e:
+        kb.solve()
+    assert e.value.code == _lib.DEVICE_ERROR and "index check" in str(e.value) and "entry out of range" in str(e.value)
+    kb.set_schedule(debug_inject=0)
+    kb.solve()
+    again = kb.results()
+    assert np.array_equal(again["xs"], good["xs"]) and np.array_equal(again["ik_iters"], good["ik_iters"])

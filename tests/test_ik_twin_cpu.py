@@ -157,3 +157,39 @@ def test_batch_is_thread_count_independent(solo):
     a = ic.solve_wb_batch(m, wb, X, nthreads=1)
     b = ic.solve_wb_batch(m, wb, X, nthreads=4)
     assert np.array_equal(a["xs"], b["xs"]) and np.array_equal(a["iters"], b["iters"])
+
+
+IK_GOLDEN = sorted(__import__("glob").glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ik_*.npz")))
+
+
+@pytest.mark.parametrize("path", IK_GOLDEN, ids=[os.path.basename(p)[:-4] for p in IK_GOLDEN])
+def test_twin_and_generator_reproduce_the_ik_golden_fixtures(path, solo, go2):
+    """tests/golden/ik_*.npz (make_golden_ik.py): the problem generator + URDF-derived model still produce the committed inputs,
+    and the compiled twin still takes the committed discrete path (iterations, every accepted step length and regularisation
+    value) to the committed trajectories.  Includes a Go2 problem that runs to SolverDDP's maxiter."""
+    from tests.golden import make_golden_ik as mg
+    g = np.load(path)
+    robot = str(g["robot"])
+    B = g["x0"].shape[0]
+    model, wb = mg.wb_batch(robot, B)
+    m = (go2 if robot == "go2" else solo)[1]
+    wb.dyn.x_init[:] = ic.centroidal_state(m, wb.x)
+    X = oracle_c.solve_batch(wb.dyn, num_iters=10)["X"]
+    assert np.all(rel_l2(X, g["X"]) < 1e-9)
+    inp = mg.ik_inputs(model, wb, g["X"])
+    for k in ("x0", "dt", "tasks", "state_w", "x_reg", "ctrl_w"):
+        assert np.array_equal(inp[k], g[k]), "generator / model drifted: " + k
+    r = ic.solve_batch(m, g["x0"], g["dt"], g["tasks"], g["state_w"], g["x_reg"], g["ctrl_w"], trace=True)
+    assert np.array_equal(r["iters"], g["iters"]) and np.array_equal(r["status"], g["status"])
+    for i in range(B):
+        n = int(g["iters"][i])
+        assert np.array_equal(r["trace"][i, :n, 1:3], g["trace"][i, :n, 1:3]), i          # regularisation, accepted step length
+        assert np.all(np.abs(r["trace"][i, :n, 0] - g["trace"][i, :n, 0]) <= 1e-10 * np.abs(g["trace"][i, :n, 0])), i
+    assert np.all(rel_l2(r["xs"].reshape(B, -1), g["xs"].reshape(B, -1)) < 1e-10)
+    assert np.all(np.abs(r["cost"] - g["cost"]) <= 1e-10 * np.abs(g["cost"]))
+    if robot == "go2":
+        assert 1 in g["status"].tolist() and g["iters"].max() == 100
+
+
+def test_ik_golden_files_present():
+    assert len(IK_GOLDEN) >= 2

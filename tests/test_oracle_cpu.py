@@ -13,7 +13,8 @@ from bunmpc_amd import problems
 from oracle import oracle_np
 from tests.util import rel_l2
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
+                if not os.path.basename(p).startswith("ik_"))                      # ik_*: whole-body fixtures (tests/test_ik_twin_cpu.py)
 
 
 def _np_solve(b, i, ref, iters):

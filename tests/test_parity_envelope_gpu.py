@@ -13,7 +13,7 @@ import pytest
 
 from bunmpc_amd import batch as bb
 from bunmpc_amd import problems, urdf_model
-from tests.util import cpu_spread, rel_l2, within_envelope
+from tests.util import cpu_spread, rel_l2, within_envelope, within_population_envelope
 
 pytestmark = pytest.mark.gpu
 ROBOTS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bunmpc_amd", "robots")
@@ -132,6 +132,62 @@ def test_full_size_go2_bound_h40(oracle, precision):
     else:
         calm = spread <= 1e-9
         assert np.median(err[calm]) <= FP32_MEDIAN and np.all(err[calm] <= FP32_MAX)
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_full_size_solo12_mixed(oracle, precision):
+    """BASELINE config 4's per-GPU share (Solo12 trot / bound / pace mixed, H = 20, B = 4096 = 32768 / 8, per-problem weights):
+    size-independent properties on every problem, a bit-identical second solve, oracle parity on a 64-problem sample inside the
+    measured envelope (bound and pace sit in the reference algorithm's chaotic regime, tests/util.py)."""
+    B = 4096
+    b = problems.make_batch("solo12_mixed", B)
+    assert b.W_X.shape[0] == B and len(set(b.gait_id.tolist())) == 3          # the per-problem-weights path, all three gaits
+    dev = bb.DeviceBatch(b, num_iters=10, precision=precision)
+    dev.solve()
+    got = dev.results()
+    assert bb._lib.lib().bmpc_biconvex_last_kernel_name() == (b"biconvex_admm_kernel" if precision == "f64" else b"biconvex_admm_kernel_f32")
+    _centroidal_invariants(b, got, oracle, b.mu)
+    dev.solve()
+    again = dev.results()
+    for k in "XFP":
+        assert np.array_equal(again[k], got[k])
+    sub = np.arange(0, B, 64)
+    ref, spread = cpu_spread(b.take(sub), 10, oracle)
+    err, bound = within_envelope({k: got[k][sub] for k in "XF"}, ref, spread)
+    assert np.array_equal(got["stats"][sub][:, [0, 5]], ref["stats"][:, [0, 5]])
+    calm = spread <= 1e-9
+    print("solo12_mixed B=4096 %s: sampled parity calm %d problems max %.2e | chaotic %d problems max %.2e (CPU spread max %.2e)"
+          % (precision, calm.sum(), err[calm].max() if calm.any() else 0.0, (~calm).sum(), err[~calm].max() if (~calm).any() else 0.0, spread.max()))
+    if precision == "f64":
+        err, bound, own = within_population_envelope({k: got[k][sub] for k in "XF"}, ref, spread)
+        assert np.all(err <= bound) and own >= 0.9, (err[err > bound], own)
+        assert np.all(err[calm] < 1e-12)
+        assert np.array_equal(got["stats"][sub][calm], ref["stats"][calm])    # calm problems: the oracle's whole discrete path
+    else:
+        assert np.median(err[calm]) <= FP32_MEDIAN and np.all(err[calm] <= FP32_MAX)
+
+
+def test_config2_batch_1024_through_the_default_dispatch(oracle):
+    """BASELINE config 2 (Solo12 trot, H = 20, B = 1024 perturbed initial conditions, fp64) exactly as a caller gets it: no
+    mapping override, so the dispatch takes the one-problem-per-wave kernel (asserted) -- invariants on all 1024, sampled oracle
+    parity with the oracle's discrete path."""
+    B = 1024
+    b = problems.make_batch("solo12_trot", B)
+    dev = bb.DeviceBatch(b, num_iters=10)
+    dev.solve()
+    assert bb._lib.lib().bmpc_biconvex_last_kernel_name() == b"biconvex_latency_kernel"
+    got = dev.results()
+    _centroidal_invariants(b, got, oracle, b.mu)
+    sub = np.arange(0, B, 16)
+    ref, spread = cpu_spread(b.take(sub), 10, oracle, with_numpy=False)
+    err, bound = within_envelope({k: got[k][sub] for k in "XF"}, ref, spread)
+    assert np.array_equal(got["stats"][sub], ref["stats"])
+    print("solo12_trot B=1024 default dispatch: sampled parity median %.2e max %.2e" % (np.median(err), err.max()))
+    assert np.all(err <= bound) and np.median(err) < 1e-12
+    dev.solve()
+    again = dev.results()
+    for k in "XFP":
+        assert np.array_equal(again[k], got[k])
 
 
 def test_full_size_go2_h60_kinodyn(oracle):
