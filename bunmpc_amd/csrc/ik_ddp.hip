@@ -31,6 +31,10 @@
 #include "rbd_quad.h"
 #include "lds_batch.h"
 
+#ifndef BWD_PREFETCH_ROW
+#define BWD_PREFETCH_ROW 0
+#endif
+
 namespace bunmpc {
 namespace {
 
@@ -707,40 +711,58 @@ __global__ __launch_bounds__(64 * NWB) void ik_backward_kernel(const IkBatchArgs
             wave_sync();
         }
 
+        // What a node reads from the workspace -- its L_xx row (36 doubles per lane), L_x / L_u / L_uu entries, the Jintegrate blocks
+        // and its gap -- is requested ONE NODE AHEAD: issued at the top of node t + 1, it has the whole of that node (~20K cycles)
+        // to arrive.  Loaded at the top of its own node the row had ~5K cycles before its first use and the small vectors none
+        // (a global-memory latency exposed twice per node: 3.4K + 2.1K of 22.5K cycles, tools/bwd_profile.py).
+        double lr[kNDX], lx_t, lu_t, luu_t, a6_t, b6_t, fs_t, dt;
+        auto fetch_node = [&](int t, double (&o_lr)[kNDX], double &o_lx, double &o_lu, double &o_luu, double &o_a6, double &o_b6, double &o_fs,
+                              double &o_dt) {
+            o_dt = a.dt[b * T + t];
+            o_lx = row ? ws[L.Lx + (long)t * kNDX + r] : 0.0;
+            o_lu = ul ? ws[L.Lu + (long)t * kNV + uq] : 0.0;
+            o_luu = lane >= kNDX && lane < kNDX + kNV ? ws[L.Luu + (long)t * kNV + lane - kNDX] : 0.0;   // on the lane of Q_uu row p
+#if BWD_PREFETCH_ROW
+            const double *Lr = ws + L.Lxx + (long)t * kNDX * kNDX + (long)r * kNDX;
+            UNROLL_RBD for (int j = 0; j < kNDX; ++j) o_lr[j] = Lr[j];
+#endif
+            o_a6 = lane < 36 ? ws[L.A6 + (long)t * 36 + lane] : 0.0;
+            o_b6 = lane < 36 ? ws[L.B6 + (long)t * 36 + lane] : 0.0;
+            o_fs = row ? ws[L.fs + (long)t * kNDX + r] : 0.0;
+        };
+        if (T > 0) fetch_node(T - 1, lr, lx_t, lu_t, luu_t, a6_t, b6_t, fs_t, dt);
         for (int t = T - 1; t >= 0; --t) {
-            const double dt = a.dt[b * T + t];
 #ifdef BWD_PROFILE
             pt0 = __builtin_readcyclecounter();
 #endif
-            // every global read of this node is issued here, so that the L_xx row (36 doubles per lane) travels while the
-            // F_x^T products and the transposition run
-            const double lx_t = row ? ws[L.Lx + (long)t * kNDX + r] : 0.0;
-            const double lu_t = ul ? ws[L.Lu + (long)t * kNV + uq] : 0.0;
-            const double luu_t = lane >= kNDX && lane < kNDX + kNV ? ws[L.Luu + (long)t * kNV + lane - kNDX] : 0.0;   // on the lane of Q_uu row p
-            double lr[kNDX];
-            {
+            if (lane < 36) { s.A6[lane] = a6_t; s.B6[lane] = b6_t; }
+            if (row) { s.Vx[r] = vx; s.fs[r] = fs_t; }
+            const double dt_t = dt;      // (this node's; the variables above are about to be overwritten by the requests for node t - 1)
+            double nlr[kNDX], nlx = 0.0, nlu = 0.0, nluu = 0.0, na6 = 0.0, nb6 = 0.0, nfs = 0.0, ndt = 0.0;
+            if (t > 0) fetch_node(t - 1, nlr, nlx, nlu, nluu, na6, nb6, nfs, ndt);
+#if !BWD_PREFETCH_ROW
+            {    // the row itself at the top of its own node (a node ahead it costs 72 more registers: the kernel then spills and is slower)
                 const double *Lr = ws + L.Lxx + (long)t * kNDX * kNDX + (long)r * kNDX;
                 UNROLL_RBD for (int j = 0; j < kNDX; ++j) lr[j] = Lr[j];
             }
-            if (lane < 36) { s.A6[lane] = ws[L.A6 + (long)t * 36 + lane]; s.B6[lane] = ws[L.B6 + (long)t * 36 + lane]; }
-            if (row) { s.Vx[r] = vx; s.fs[r] = ws[L.fs + (long)t * kNDX + r]; }
+#endif
             wave_sync();
             PSTAMPV(0, m[0])
-            apply_FxT(m, a6_addr, b6_addr, dt);                  // column r of N = F_x^T V
+            apply_FxT(m, a6_addr, b6_addr, dt_t);                  // column r of N = F_x^T V
             if (row) { UNROLL_RBD for (int i = 0; i < kNDX; ++i) s.N[i * LD + r] = m[i]; }
             wave_sync();
             PSTAMPV(1, m[0])
             lds_read_row36(row_addr, m);                         // row r of N
-            apply_FxT(m, a6_addr, b6_addr, dt);                  // row r of G = N F_x
+            apply_FxT(m, a6_addr, b6_addr, dt_t);                  // row r of G = N F_x
             PSTAMPV(2, m[35])
             // Q_x = L_x + F_x^T V_x ;  Q_u = L_u + dt (F_x^T V_x)[v]
             double fvx;
             if (r < 6) { fvx = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) fvx += s.A6[6 * c + r] * s.Vx[c]; }
             else if (r < kNV) fvx = s.Vx[r];
-            else if (r < kNV + 6) { fvx = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) fvx += s.B6[6 * c + (r - kNV)] * s.Vx[c]; fvx = dt * fvx + s.Vx[r]; }
-            else fvx = dt * s.Vx[r - kNV] + s.Vx[r];
+            else if (r < kNV + 6) { fvx = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) fvx += s.B6[6 * c + (r - kNV)] * s.Vx[c]; fvx = dt_t * fvx + s.Vx[r]; }
+            else fvx = dt_t * s.Vx[r - kNV] + s.Vx[r];
             const double qx = lx_t + fvx;
-            const double qu = ul ? lu_t + dt * fvx : 0.0;   // Q_u[q] on lane 18 + q
+            const double qu = ul ? lu_t + dt_t * fvx : 0.0;   // Q_u[q] on lane 18 + q
             // The factorisation and the forward substitutions in one elimination.  Y^T = Q_xu L^-T obeys the recurrence of the
             // rows of L itself:  Y^T[r][j] = (Q_xu[r][j] - sum_{k<j} Y^T[r][k] L[j][k]) / L[j][j],  so the rows of Q_xu ride along
             // as extra rows of the matrix being factorised -- [Q_xu (lanes 0..35); Q_uu (lanes 36..53); Q_u^T (lane 54)], one row
@@ -750,9 +772,9 @@ __global__ __launch_bounds__(64 * NWB) void ik_backward_kernel(const IkBatchArgs
             double al[kNV], quv[kNV];
             const bool urow = lane >= kNDX && lane < kQuLane;
             UNROLL_RBD for (int q = 0; q < kNV; ++q) {
-                const double xq = dt * m[kNV + q];                       // Q_xu[r][q]
+                const double xq = dt_t * m[kNV + q];                       // Q_xu[r][q]
                 quv[q] = lane_value(qu, kNV + q);
-                al[q] = urow ? dt * xq : (lane == kQuLane ? quv[q] : xq);   // Q_uu[p][q] without its diagonal term / Q_u / Q_xu
+                al[q] = urow ? dt_t * xq : (lane == kQuLane ? quv[q] : xq);   // Q_uu[p][q] without its diagonal term / Q_u / Q_xu
             }
             const double dgv = urow ? luu_t + xreg : 0.0;                // L_uu + reg of control p on lane 36 + p
             if (row) { UNROLL_RBD for (int j = 0; j < kNDX; ++j) s.N[r * LD + j] = m[j] + lr[j]; }       // Q_xx row -> LDS
@@ -903,6 +925,12 @@ __global__ __launch_bounds__(64 * NWB) void ik_backward_kernel(const IkBatchArgs
             bad = __any(bad && (row || lane < kNV));
             wave_sync();
             PSTAMPV(8, vx)
+            if (t > 0) {     // the node requested at the top becomes the current one
+#if BWD_PREFETCH_ROW
+                UNROLL_RBD for (int j = 0; j < kNDX; ++j) lr[j] = nlr[j];
+#endif
+                lx_t = nlx; lu_t = nlu; luu_t = nluu; a6_t = na6; b6_t = nb6; fs_t = nfs; dt = ndt;
+            }
             if (bad) break;
         }
         if (!bad) break;

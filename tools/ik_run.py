@@ -17,6 +17,8 @@ if len(sys.argv) > 4:
     lib.bmpc_ik_set_all_steps(int(sys.argv[4]))
 if len(sys.argv) > 5:
     lib.bmpc_ik_set_gains_wave_below(int(sys.argv[5]))
+if os.environ.get("IK_BLOCKING_WAITS"):
+    lib.bmpc_ik_set_blocking_waits(int(os.environ["IK_BLOCKING_WAITS"]))
 robot = "go2" if cfg == "go2_h60" else "solo12"
 model = urdf_model.RobotModel.from_json(open(os.path.join(ROOT, "bunmpc_amd", "robots", robot + ".json")).read())
 if cfg == "go2_h60":
@@ -35,3 +37,16 @@ for rep in range(3):
     print("solve %.2f ms, ik only %.2f ms" % ((t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3))
 r = kb.results()
 print("iters mean %.2f max %d not converged %d" % (r["ik_iters"].mean(), r["ik_iters"].max(), (r["ik_status"] != 0).sum()))
+# per-kernel split of one IK batch solve (events around every kernel of the DDP loop) and a digest of the results (to compare builds)
+import ctypes, hashlib
+lib.bmpc_ik_set_profile(1)
+kb.solve_ik_only()
+torch.cuda.synchronize()
+lib.bmpc_ik_set_profile(0)
+prof = (5 * ctypes.c_double)()
+lib.bmpc_ik_last_profile(prof)
+print("kernel ms per batch solve: state %.2f calcdiff %.2f backward %.2f forward %.2f other %.2f" % tuple(prof))
+h = hashlib.sha256()
+for k in ("xs", "us", "ik_iters", "ik_cost"):
+    h.update(np.ascontiguousarray(r[k]).tobytes())
+print("results digest", h.hexdigest()[:16], "ddp loop iterations", r["ddp_loop_iters"])
