@@ -178,6 +178,8 @@ _SIGS = {
     "bmpc_ik_set_all_steps": (_I, [_I]),
     "bmpc_ik_set_gains_wave_below": (_I, [_I]),
     "bmpc_ik_set_blocking_waits": (_I, [_I]),
+    "bmpc_ik_set_express_capacity": (_I, [_I]),
+    "bmpc_ik_set_express_near": (C.c_double, [C.c_double]),
     "bmpc_ik_batch_struct_size": (_I, []),
     "bmpc_ik_active_list_ints": (C.c_long, [C.c_long]),
     "bmpc_ik_last_profile": (None, [_P]),
@@ -200,7 +202,7 @@ IK_NODE_TASK_DOUBLES = 33
 
 class IkSched(C.Structure):
     """bmpc_ik_sched_t: per-batch scheduling thresholds (0 = process default, < 0 = never)"""
-    _fields_ = [("spec_below", C.c_int), ("all_steps_below", C.c_int), ("gains_wave_below", C.c_int), ("debug_inject", C.c_int)]
+    _fields_ = [("spec_below", C.c_int), ("all_steps_below", C.c_int), ("gains_wave_below", C.c_int), ("express_cap", C.c_int), ("debug_inject", C.c_int)]
 
 
 class IkBatch(C.Structure):

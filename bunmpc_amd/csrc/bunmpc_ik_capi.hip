@@ -141,6 +141,8 @@ int pack_tasks(const bmpc_ik *h, std::vector<double> &tasks) {
     return BMPC_OK;
 }
 
+std::atomic<double> g_express_near{1.0};   // the express lane's trigger: |Q_u|^2 below this = "within reach of the stopping threshold"
+
 bunmpc::IkBatchArgs make_args(int B, int T, int maxiter, const bmpc_model *model, const double *x0, const double *dt,
                               const double *tasks, const double *state_w, long s_sw, const double *x_reg,
                               const double *ctrl_w, long s_cw, double *ws, int *active) {
@@ -149,7 +151,8 @@ bunmpc::IkBatchArgs make_args(int B, int T, int maxiter, const bmpc_model *model
     a.x0 = x0; a.dt = dt; a.tasks = tasks; a.state_w = state_w; a.x_reg = x_reg; a.ctrl_w = ctrl_w;
     a.s_state_w = s_sw; a.s_ctrl_w = s_cw; a.ws = ws; a.active = active;
     a.s_x_reg = bunmpc::kNX; a.sn_state_w = a.sn_x_reg = a.sn_ctrl_w = 0; a.fwd_spec = 0; a.bwd_waves = 1;
-    a.list = nullptr; a.count = nullptr; a.wide = nullptr; a.wcount = nullptr; a.err = nullptr; a.iter = 0; a.n_launch = B;
+    a.list = nullptr; a.count = nullptr; a.wide = nullptr; a.wcount = nullptr; a.err = nullptr; a.near = nullptr; a.xmeta = nullptr; a.xlist = nullptr;
+    a.iter = 0; a.n_launch = B; a.near_stop = g_express_near.load();
     return a;
 }
 
@@ -169,16 +172,19 @@ std::atomic<int> g_blocking_waits{1};       // the DDP loop's host waits sleep o
 constexpr int kMaxIkCol = 63;     // T + 1 <= 64 nodes: the backward pass computes the gaps one lane per node
 
 // thresholds of ONE DDP loop: field of bmpc_ik_batch_t.sched (0 = the process default, < 0 = never, n > 0 = n)
-struct Sched { int spec_below, all_steps, gains_wave_below; int debug_inject = 0; };
+struct Sched { int spec_below, all_steps, gains_wave_below; int debug_inject = 0; int express_cap = 0; };
 int sched_pick(int field, const std::atomic<int> &dflt) { return field == 0 ? dflt.load() : field < 0 ? 0 : field; }
-Sched default_sched() { return Sched{g_spec_line_search_below.load(), g_all_steps.load(), g_gains_wave_below.load()}; }
+std::atomic<int> g_express_cap{96};         // the express lane takes at most this many problems of a batch (0 = no express lane)
+Sched default_sched() { return Sched{g_spec_line_search_below.load(), g_all_steps.load(), g_gains_wave_below.load(), 0, g_express_cap.load()}; }
 
 // Two host-mapped words and events per (device, stream), through which the kernels' active counter reaches the DDP loop.
 // Keyed by the stream, not by the host thread: a stream's publishes are ordered among themselves, so a late publish of one
 // batch can never overwrite the counter of another batch running on a different stream; and the few entries (one per stream
 // ever used) live as long as the library, whatever threads come and go (bunmpc_amd/pipeline.py starts workers per call).
 struct ActiveWord {
-    int *host[2] = {nullptr, nullptr}, *dev[2] = {nullptr, nullptr};
+    int *host[2] = {nullptr, nullptr}, *dev[2] = {nullptr, nullptr};      // four ints each: active, index-check code, list length, express taken
+    hipStream_t side = nullptr;                 // the express lane's stream (ik_fused_kernel beside the batch's own kernels)
+    hipEvent_t x_go = nullptr, x_done = nullptr;
     // evs[0]: spinning waits, evs[1]: blocking waits (hipEventBlockingSync: the waiting host thread sleeps until the interrupt --
     // with eight ranks of up to three pool threads each on a 16-core cgroup, spinning waits would fight the other ranks' loops)
     hipEvent_t evs[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
@@ -186,11 +192,14 @@ struct ActiveWord {
     int ensure() {
         if (host[0]) return BMPC_OK;
         for (int k = 0; k < 2; ++k) {
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&host[k]), 2 * sizeof(int), hipHostMallocMapped));   // [active, index-check code]
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&host[k]), 4 * sizeof(int), hipHostMallocMapped));
             HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&dev[k]), host[k], 0));
             HIP_TRY(hipEventCreateWithFlags(&evs[0][k], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&evs[1][k], hipEventDisableTiming | hipEventBlockingSync));
         }
+        HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&x_go, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&x_done, hipEventDisableTiming | hipEventBlockingSync));
         return BMPC_OK;
     }
 };
@@ -241,6 +250,15 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run, const
     // one chunk late: the next chunk is enqueued BEFORE the host waits for the counter of the one before, so the queue
     // never drains while the host turns around (at the end one chunk of no-op kernels runs out on its own).
     constexpr int kTailChunk = 3;
+    // The express lane (ik_select_kernel / ik_fused_kernel): in front of the early iterations a one-workgroup kernel looks at the
+    // batch and -- once, when it finds it converging fast with a thin tail of laggards -- moves the laggards-to-be off the active
+    // list; the fused kernel enqueued behind it on the side stream runs them to the end at their own pace, on CUs of their own,
+    // while the batch goes on without them.  The decision is the device's (the host would learn of it an iteration late); the
+    // host enqueues the pair until a look tells it that the lane has taken its problems, or the window has passed.
+    constexpr int kExpressFirstIter = 2, kExpressLastIter = 12;
+    const int express_cap = a.list && a.B >= 64 ? sched.express_cap : 0;
+    bool express_taken = false;
+    int express_enqueued = 0;
     int active = a.B, it = 0, it_end[2] = {0, 0};
     auto enqueue_chunk = [&](int slot) -> int {
         const int chunk = active <= sched.spec_below ? kTailChunk : 1;
@@ -249,6 +267,14 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run, const
         a.n_launch = active;        // the host's latest look at the counter: an upper bound of the active list's length
         for (int k = 0; k < chunk && it < a.maxiter; ++k, ++it) {
             a.iter = it;
+            if (express_cap > 0 && !express_taken && it >= kExpressFirstIter && it <= kExpressLastIter) {
+                HIP_TRY(bunmpc::ik_launch_select(a, express_cap, st));
+                HIP_TRY(hipEventRecord(w.x_go, st));
+                HIP_TRY(hipStreamWaitEvent(w.side, w.x_go, 0));
+                HIP_TRY(bunmpc::ik_launch_fused_express(a, express_cap, w.side));
+                HIP_TRY(hipEventRecord(w.x_done, w.side));
+                ++express_enqueued;
+            }
             if (int rc = stamp()) return rc;
             HIP_TRY(bunmpc::ik_launch_state(a, st));
             if (int rc = stamp()) return rc;
@@ -259,20 +285,23 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run, const
             HIP_TRY(bunmpc::ik_launch_forward(a, st));
             if (int rc = stamp()) return rc;
         }
-        HIP_TRY(bunmpc::ik_launch_publish_active(a.active, a.err, w.dev[slot], st));
+        HIP_TRY(bunmpc::ik_launch_publish_active(a, it, w.dev[slot], st));
         HIP_TRY(hipEventRecord(ev[slot], st));
         it_end[slot] = it;
         return BMPC_OK;
     };
-    int slot = 0, it_done = 0, index_err = 0;
+    int slot = 0, it_done = 0, index_err = 0, all_active = a.B;
     if (a.maxiter > 0 && active > 0) {
         if (int rc = enqueue_chunk(slot)) return rc;
         for (;;) {
             const bool more = it < a.maxiter;
             if (more) { if (int rc = enqueue_chunk(slot ^ 1)) return rc; }
             HIP_TRY(hipEventSynchronize(ev[slot]));
-            active = static_cast<volatile int *>(w.host[slot])[0];
-            index_err = static_cast<volatile int *>(w.host[slot])[1];
+            const volatile int *hw = static_cast<volatile int *>(w.host[slot]);
+            all_active = hw[0];
+            index_err = hw[1];
+            active = hw[2] >= 0 ? hw[2] : hw[0];     // what the batch's own kernels still run over (the express lane's problems are not on the list)
+            express_taken = express_taken || hw[3] != 0;
             it_done = it_end[slot];
             if (index_err) active = 0;       // an index of the list code was out of range: stop, report below
             if (active <= 0 || !more) {
@@ -285,10 +314,21 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run, const
         }
     }
     if (iters_run) *iters_run = it_done;     // iterations up to the look that found every problem done (not the chunk enqueued ahead)
+    if (express_enqueued > 0) {
+        // the lane's kernel ends when its last problem has: the caller's stream is ordered behind it, and one more look tells
+        // whether it left an error code (or a problem) behind
+        HIP_TRY(hipStreamWaitEvent(st, w.x_done, 0));
+        HIP_TRY(bunmpc::ik_launch_publish_active(a, it, w.dev[0], st));
+        HIP_TRY(hipEventRecord(ev[0], st));
+        HIP_TRY(hipEventSynchronize(ev[0]));
+        const volatile int *hw = static_cast<volatile int *>(w.host[0]);
+        all_active = hw[0];
+        if (!index_err) index_err = hw[1];
+    }
     if (index_err) {
         static const char *what[] = {"", "active-list entry out of range", "active-list length out of range", "active-list append past its end",
-                                     "wide-list entry out of range"};
-        return ik_fail(BMPC_DEVICE_ERROR, std::string("IK-DDP index check failed: ") + what[index_err < 5 ? index_err : 0] +
+                                     "wide-list entry out of range", "the fused kernel's tick watchdog fired"};
+        return ik_fail(BMPC_DEVICE_ERROR, std::string("IK-DDP index check failed: ") + what[index_err < 6 ? index_err : 0] +
                        " (code " + std::to_string(index_err) + "); results of this batch are invalid");
     }
     if (prof && !pev.empty()) {
@@ -458,6 +498,8 @@ int bmpc_ik_selftest_state_ops(const double *x0, const double *x1, const double 
 }
 int bmpc_ik_set_all_steps(int n_active) { return g_all_steps.exchange(n_active); }
 int bmpc_ik_set_blocking_waits(int on) { return g_blocking_waits.exchange(on != 0); }
+int bmpc_ik_set_express_capacity(int n) { return g_express_cap.exchange(n); }
+double bmpc_ik_set_express_near(double stop) { return g_express_near.exchange(stop); }
 int bmpc_ik_batch_struct_size(void) { return (int)sizeof(bmpc_ik_batch_t); }
 int bmpc_ik_set_speculative_below(int n_active) { return g_spec_line_search_below.exchange(n_active); }
 double bmpc_model_total_mass(const bmpc_model_t *m) { return m ? m->host.total_mass : 0.0; }
@@ -670,10 +712,11 @@ int bmpc_ik_solve_batch_device(const bmpc_ik_batch_t *d, void *hip_stream) {
                               d->ctrl_w, d->s_ctrl_w, d->ws, d->active);
     a.s_x_reg = d->s_x_reg ? d->s_x_reg : kNX;
     a.sn_state_w = d->sn_state_w; a.sn_x_reg = d->sn_x_reg; a.sn_ctrl_w = d->sn_ctrl_w;
-    if (d->active_list) { a.list = d->active_list; a.count = a.list + 2 * (long)d->B; a.wcount = a.count + 2; a.wide = a.wcount + 2; a.err = a.wide + 2 * kWideMax; }
+    if (d->active_list) { a.list = d->active_list; a.count = a.list + 2 * (long)d->B; a.wcount = a.count + 2; a.wide = a.wcount + 2; a.err = a.wide + 2 * kWideMax;
+                          a.near = a.err + 2; a.xmeta = a.near + 2; a.xlist = a.xmeta + 4; }
     int iters = 0;
     const Sched sched{sched_pick(d->sched.spec_below, g_spec_line_search_below), sched_pick(d->sched.all_steps_below, g_all_steps),
-                      sched_pick(d->sched.gains_wave_below, g_gains_wave_below), d->sched.debug_inject};
+                      sched_pick(d->sched.gains_wave_below, g_gains_wave_below), d->sched.debug_inject, sched_pick(d->sched.express_cap, g_express_cap)};
     int rc = run_ddp(a, static_cast<hipStream_t>(hip_stream), &iters, sched);
     if (d->iters_run) *d->iters_run = iters;
     return rc;

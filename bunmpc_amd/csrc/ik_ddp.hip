@@ -157,8 +157,10 @@ __global__ void ik_init_kernel(const IkBatchArgs a) {
     s[S_COST] = 0; s[S_XREG] = 1e-9; s[S_D1] = 0; s[S_D2] = 0; s[S_STOP] = 0; s[S_FEAS] = 0; s[S_WASFEAS] = 0;
     s[S_DONE] = 0; s[S_ITERS] = 0; s[S_RECALC] = 1; s[S_STATUS] = 0; s[S_WIDE] = 0; s[S_WIDENOW] = 0;
     ws[L.arrive] = 0.0;          // (read as an unsigned counter)
+    for (int k = 0; k < 8; ++k) ws[L.Qu + k] = 0.0;      // the fused kernel's telemetry (the Qu slot is unused by the solver)
     if (a.list) a.list[b] = (int)b;
-    if (b == 0) { *a.active = a.B; if (a.count) { a.count[0] = a.B; a.count[1] = 0; a.wcount[0] = 0; a.wcount[1] = 0; a.err[0] = 0; a.err[1] = 0; } }
+    if (b == 0) { *a.active = a.B; if (a.count) { a.count[0] = a.B; a.count[1] = 0; a.wcount[0] = 0; a.wcount[1] = 0; a.err[0] = 0; a.err[1] = 0; a.near[0] = 0; a.near[1] = 0;
+                                               for (int k = 0; k < 4; ++k) a.xmeta[k] = 0; } }
 }
 
 // --------------------------------------------------------------------------- calcDiff ---
@@ -230,21 +232,9 @@ __device__ __forceinline__ double node_state_terms(const IkBatchArgs &a, long b,
     return cost;
 }
 
-// ... for all nodes of all problems, ONE LANE PER NODE, launched before ik_calcdiff_kernel.  Inside that kernel (where it used
-// to run, on lanes 0 and 32 of wave 1) this chain kept two lanes of a wave busy, and in the bulk iterations -- where
-// calcdiff is bound by instruction issue -- those two lanes cost a quarter of the workgroup's issue slots; here 64 nodes
-// share every instruction.  One code path whatever the number of active problems, so a problem's results do not depend
-// on its batch (the few microseconds of an extra launch per tail iteration are the price).
-__global__ __launch_bounds__(64) void ik_state_kernel(const IkBatchArgs a) {
+// The scalar chain of node tw of problem b (ik_state_kernel's lane; a lane of the fused kernel's first producer step)
+__device__ __forceinline__ void state_node(const IkBatchArgs &a, long b, int tw, double *ws, const IkLayout &L) {
     const int nn = a.T + 1;
-    const long idx = (long)blockIdx.x * 64 + threadIdx.x;
-    if (idx == 0 && a.count) { a.count[(a.iter + 1) & 1] = 0; a.wcount[(a.iter + 1) & 1] = 0; }     // the lists this iteration's forward pass will fill
-    const long b = slot_problem(a, idx / nn);
-    const int tw = (int)(idx % nn);
-    if (b < 0) return;
-    const IkLayout L = IkLayout::make(a.T);
-    double *ws = a.ws + b * L.total;
-    if (ws[L.scal + S_DONE] != 0.0 || ws[L.scal + S_RECALC] == 0.0) return;
     double x[kNX], u[kNV], rs[kNDX], Jl[36];
     UNROLL_RBD for (int i = 0; i < kNX; ++i) x[i] = ws[L.xs + (long)tw * kNX + i];
     UNROLL_RBD for (int i = 0; i < kNV; ++i) u[i] = tw == a.T ? 0.0 : ws[L.us + (long)tw * kNV + i];
@@ -256,138 +246,114 @@ __global__ __launch_bounds__(64) void ik_state_kernel(const IkBatchArgs a) {
     ws[L.ncs + tw] = cost;
 }
 
-// Workgroup = two waves for TWO nodes of a problem.  Wave 0: lanes 0..17 (node A) and 32..49 (node B) each walk their
-// own part of the robot once (base lanes the base body, joint lanes their leg), the five part sums of a node meet in
-// LDS, every lane finishes its column.  Wave 1, meanwhile, on lanes 0 and 32: the state residual with its Jlog6 block
-// and the Euler step with its Jintegrate blocks (a different instruction stream, so it would serialise inside wave
-// 0).  Then wave w assembles the Gauss-Newton L_x / L_xx of node w, lane j = column j.  Two nodes share every
-// instruction of the walk: the walk keeps 36 of 64 lanes busy instead of 18.
-__global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a) {
-    __shared__ CalcLds s;
-    const int nn = a.T + 1, groups = (nn + kCalcNodes - 1) / kCalcNodes;
-    const long b = slot_problem(a, blockIdx.x / groups);
+// ... for all nodes of all problems, ONE LANE PER NODE, launched before ik_calcdiff_kernel.  Inside that kernel (where it used
+// to run, on lanes 0 and 32 of wave 1) this chain kept two lanes of a wave busy, and in the bulk iterations -- where
+// calcdiff is bound by instruction issue -- those two lanes cost a quarter of the workgroup's issue slots; here 64 nodes
+// share every instruction.  One code path whatever the number of active problems, so a problem's results do not depend
+// on its batch (the few microseconds of an extra launch per tail iteration are the price).
+__global__ __launch_bounds__(64) void ik_state_kernel(const IkBatchArgs a) {
+    const int nn = a.T + 1;
+    const long idx = (long)blockIdx.x * 64 + threadIdx.x;
+    if (idx == 0 && a.count) { a.count[(a.iter + 1) & 1] = 0; a.wcount[(a.iter + 1) & 1] = 0; a.near[(a.iter + 1) & 1] = 0; }     // the lists this iteration's forward pass will fill
+    const long b = slot_problem(a, idx / nn);
+    const int tw = (int)(idx % nn);
     if (b < 0) return;
-    const int t0 = (blockIdx.x % groups) * kCalcNodes, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const IkLayout L = IkLayout::make(a.T);
     double *ws = a.ws + b * L.total;
     if (ws[L.scal + S_DONE] != 0.0 || ws[L.scal + S_RECALC] == 0.0) return;
-#ifdef BWD_PROFILE
-    long long pc[6] = {0, 0, 0, 0, 0, 0}, pt0 = __builtin_readcyclecounter();
-#endif
+    state_node(a, b, tw, ws, L);
+}
+
+// ---- the pieces of the derivative pass of a node, shared by ik_calcdiff_kernel (two waves for two nodes) and the fused
+// kernel's producer waves (one wave for two nodes, the pieces one after the other): same code, same arithmetic, same bits.
+// (1) a lane's part of the robot walk (lanes hl < 18 of a node's half-wave): parts published to the node's LDS block
+__device__ __forceinline__ void calc_walk(const RobotModelDev &m, CalcNode &qw, const NodeTasks &tkw, int hl, double (&Rb)[9], double (&pb)[3],
+                                          double (&Vb)[6], PartWalk &pw) {
+    int fid[kFrameSlots];
+    UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) fid[f] = tkw.frame_w(f) != 0.0 ? tkw.frame_id(f) : -1;
+    quad_part_walk(m, qw.x, fid, hl, Rb, pb, Vb, pw);
+    const bool leg_pub = hl >= 6 && (hl - 6) % kLegJoints == 0;
+    if (hl == 0 || leg_pub) {   // one publisher per part
+        double *pp = qw.parts[hl == 0 ? kLegs : (hl - 6) / kLegJoints];
+        pp[0] = pw.part.m;
+        UNROLL_RBD for (int c = 0; c < 3; ++c) pp[1 + c] = pw.part.h1[c];
+        UNROLL_RBD for (int c = 0; c < 6; ++c) { pp[4 + c] = pw.part.I[c]; pp[10 + c] = pw.hpart[c]; }
+        UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
+            if (pw.fhit[f]) { UNROLL_RBD for (int c = 0; c < 3; ++c) qw.fx[f][c] = pw.fx[f][c]; }
+    }
+}
+// (2) what ik_state_kernel / state_node left for node tw: state residual, its Jlog6 block (transposed), the state + control cost
+__device__ __forceinline__ void calc_fetch_state(CalcNode &qw, const double *ws, const IkLayout &L, int tw, int hl) {
+    for (int i = hl; i < kNDX; i += 32) {
+        qw.rs[i] = ws[L.nrs + (long)tw * kNDX + i];
+        (&qw.JlT[0][0])[i] = ws[L.njl + (long)tw * 36 + i];      // stored transposed already
+    }
+    if (hl == 0) qw.cost_sc = ws[L.ncs + tw];
+}
+// (3) robot totals from the five parts, then this lane's column of the residual Jacobian (and the residuals on lane 0)
+__device__ __forceinline__ void calc_columns(const RobotModelDev &m, CalcNode &qw, const NodeTasks &tkw, int hl, PartWalk &pw) {
+    Comp call; double hO[6];
     {
-        const int *src = reinterpret_cast<const int *>(a.model);
-        int *dst = reinterpret_cast<int *>(&s.m);
-        for (int i = threadIdx.x; i < (int)(sizeof(RobotModelDev) / sizeof(int)); i += 128) dst[i] = src[i];
-    }
-    const RobotModelDev &m = s.m;
-    const double *state_w0 = batch_ptr(a.state_w, a.s_state_w, b), *ctrl_w0 = batch_ptr(a.ctrl_w, a.s_ctrl_w, b);
-    const double *x_reg0 = a.x_reg + b * a.s_x_reg;
-    {   // states and controls of both nodes: wave w stages node w
-        const int t = t0 + wave;
-        if (t < nn) {
-            CalcNode &q = s.nd[wave];
-            if (lane < kNX) q.x[lane] = ws[L.xs + (long)t * kNX + lane];
-            if (lane < kNV) q.u[lane] = t == a.T ? 0.0 : ws[L.us + (long)t * kNV + lane];
-        }
-    }
-    __syncthreads();
-    PSTAMP(0)
-    // ---- walk phase: node index = half of the wave
-    const int hs = lane >> 5, hl = lane & 31, tw = t0 + hs;
-    const bool wvalid = tw < nn;
-    CalcNode &qw = s.nd[hs];
-    NodeTasks tkw{a.tasks + (b * nn + (wvalid ? tw : t0)) * kNodeTaskDoubles};
-    const bool terminal_w = tw == a.T;
-    const double dtw = (terminal_w || !wvalid) ? 0.0 : a.dt[b * a.T + tw];
-    PartWalk pw;
-    double Rb[9], pb[3], Vb[6];
-    if (wave == 0 && wvalid && hl < kNV) {
-        int fid[kFrameSlots];
-        UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) fid[f] = tkw.frame_w(f) != 0.0 ? tkw.frame_id(f) : -1;
-        quad_part_walk(m, qw.x, fid, hl, Rb, pb, Vb, pw);
-        const bool leg_pub = hl >= 6 && (hl - 6) % kLegJoints == 0;
-        if (hl == 0 || leg_pub) {   // one publisher per part
-            double *pp = qw.parts[hl == 0 ? kLegs : (hl - 6) / kLegJoints];
-            pp[0] = pw.part.m;
-            UNROLL_RBD for (int c = 0; c < 3; ++c) pp[1 + c] = pw.part.h1[c];
-            UNROLL_RBD for (int c = 0; c < 6; ++c) { pp[4 + c] = pw.part.I[c]; pp[10 + c] = pw.hpart[c]; }
-            UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
-                if (pw.fhit[f]) { UNROLL_RBD for (int c = 0; c < 3; ++c) qw.fx[f][c] = pw.fx[f][c]; }
-        }
-    } else if (wave == 1 && wvalid) {   // state residual, its Jlog6 block (transposed) and the state + control cost: from ik_state_kernel
-        for (int i = hl; i < kNDX; i += 32) {
-            qw.rs[i] = ws[L.nrs + (long)tw * kNDX + i];
-            (&qw.JlT[0][0])[i] = ws[L.njl + (long)tw * 36 + i];      // stored transposed already
-        }
-        if (hl == 0) qw.cost_sc = ws[L.ncs + tw];
-    }
-    __syncthreads();
-    PSTAMP(1)
-    if (wave == 0 && wvalid && hl < kNV) {   // robot totals from the five parts, then this lane's column
-        Comp call; double hO[6];
-        {
-            double2_t pa[20], pb2[20];
-            lds_read_b128x20(lds_offset(qw.parts), pa);
-            lds_read_b128x20(lds_offset(qw.parts) + 320, pb2);
-            double tot[kPartDoubles];
-            UNROLL_RBD for (int k = 0; k < kPartDoubles; ++k) {
-                double acc = 0.0;
-                UNROLL_RBD for (int q = 0; q < kParts; ++q) {
-                    const int e = q * kPartDoubles + k;   // element index in the 80-double block
-                    const double2_t v2 = e < 40 ? pa[e >> 1] : pb2[(e - 40) >> 1];
-                    acc += (e & 1) ? v2.y : v2.x;
-                }
-                tot[k] = acc;
+        double2_t pa[20], pb2[20];
+        lds_read_b128x20(lds_offset(qw.parts), pa);
+        lds_read_b128x20(lds_offset(qw.parts) + 320, pb2);
+        double tot[kPartDoubles];
+        UNROLL_RBD for (int k = 0; k < kPartDoubles; ++k) {
+            double acc = 0.0;
+            UNROLL_RBD for (int q = 0; q < kParts; ++q) {
+                const int e = q * kPartDoubles + k;   // element index in the 80-double block
+                const double2_t v2 = e < 40 ? pa[e >> 1] : pb2[(e - 40) >> 1];
+                acc += (e & 1) ? v2.y : v2.x;
             }
-            call.m = tot[0];
-            UNROLL_RBD for (int c = 0; c < 3; ++c) call.h1[c] = tot[1 + c];
-            UNROLL_RBD for (int c = 0; c < 6; ++c) { call.I[c] = tot[4 + c]; hO[c] = tot[10 + c]; }
+            tot[k] = acc;
         }
-        const double M = call.m, iM = 1.0 / M;
-        double com[3], t3[3], hg[6];
-        UNROLL_RBD for (int c = 0; c < 3; ++c) com[c] = call.h1[c] * iM;
-        cross3(com, hO, t3);
-        UNROLL_RBD for (int c = 0; c < 3; ++c) { hg[c] = hO[c]; hg[3 + c] = hO[3 + c] - t3[c]; }
-        if (hl < 6) { pw.cs = call; UNROLL_RBD for (int c = 0; c < 6; ++c) pw.hs[c] = hO[c]; }   // base columns move the whole robot
-        Column c;
-        quad_col_finish(pw, M, com, hO, c);
-        double *cq = qw.Jt[hl], *cv = qw.Jt[kNV + hl];
-        UNROLL_RBD for (int k = 0; k < 6; ++k) { cq[k] = c.dh[k]; cv[k] = c.ag[k]; }
-        UNROLL_RBD for (int k = 0; k < 3; ++k) cq[6 + k] = c.jc[k];
+        call.m = tot[0];
+        UNROLL_RBD for (int c = 0; c < 3; ++c) call.h1[c] = tot[1 + c];
+        UNROLL_RBD for (int c = 0; c < 6; ++c) { call.I[c] = tot[4 + c]; hO[c] = tot[10 + c]; }
+    }
+    const double M = call.m, iM = 1.0 / M;
+    double com[3], t3[3], hg[6];
+    UNROLL_RBD for (int c = 0; c < 3; ++c) com[c] = call.h1[c] * iM;
+    cross3(com, hO, t3);
+    UNROLL_RBD for (int c = 0; c < 3; ++c) { hg[c] = hO[c]; hg[3 + c] = hO[3 + c] - t3[c]; }
+    if (hl < 6) { pw.cs = call; UNROLL_RBD for (int c = 0; c < 6; ++c) pw.hs[c] = hO[c]; }   // base columns move the whole robot
+    Column c;
+    quad_col_finish(pw, M, com, hO, c);
+    double *cq = qw.Jt[hl], *cv = qw.Jt[kNV + hl];
+    UNROLL_RBD for (int k = 0; k < 6; ++k) { cq[k] = c.dh[k]; cv[k] = c.ag[k]; }
+    UNROLL_RBD for (int k = 0; k < 3; ++k) cq[6 + k] = c.jc[k];
+    UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) {
+        double j3[3] = {0, 0, 0};
+        if (tkw.frame_w(f) != 0.0 && quad_supports(m, tkw.frame_id(f), hl)) {
+            const double fxf[3] = {qw.fx[f][0], qw.fx[f][1], qw.fx[f][2]};
+            cross3(c.S + 3, fxf, j3);
+            UNROLL_RBD for (int k = 0; k < 3; ++k) j3[k] += c.S[k];
+        }
+        UNROLL_RBD for (int k = 0; k < 3; ++k) cq[9 + 3 * f + k] = j3[k];
+    }
+    cq[kRes] = 0.0;
+    UNROLL_RBD for (int k = 6; k < kResLd; ++k) cv[k] = 0.0;
+    if (hl == 0) {   // residuals and their cost
+        double cost = 0.0, acc = 0.0;
+        UNROLL_RBD for (int k = 0; k < 6; ++k) { const double rr = hg[k] - tkw.mom_ref()[k]; qw.res[k] = rr; acc += rr * rr; }
+        cost += tkw.mom_w() * 0.5 * acc;
+        acc = 0.0;
+        UNROLL_RBD for (int k = 0; k < 3; ++k) { const double rr = com[k] - tkw.com_ref()[k]; qw.res[6 + k] = rr; acc += rr * rr; }
+        cost += tkw.com_w() * 0.5 * acc;
         UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) {
-            double j3[3] = {0, 0, 0};
-            if (tkw.frame_w(f) != 0.0 && quad_supports(m, tkw.frame_id(f), hl)) {
-                const double fxf[3] = {qw.fx[f][0], qw.fx[f][1], qw.fx[f][2]};
-                cross3(c.S + 3, fxf, j3);
-                UNROLL_RBD for (int k = 0; k < 3; ++k) j3[k] += c.S[k];
-            }
-            UNROLL_RBD for (int k = 0; k < 3; ++k) cq[9 + 3 * f + k] = j3[k];
-        }
-        cq[kRes] = 0.0;
-        UNROLL_RBD for (int k = 6; k < kResLd; ++k) cv[k] = 0.0;
-        if (hl == 0) {   // residuals and their cost
-            double cost = 0.0, acc = 0.0;
-            UNROLL_RBD for (int k = 0; k < 6; ++k) { const double rr = hg[k] - tkw.mom_ref()[k]; qw.res[k] = rr; acc += rr * rr; }
-            cost += tkw.mom_w() * 0.5 * acc;
+            const double w = tkw.frame_w(f);
             acc = 0.0;
-            UNROLL_RBD for (int k = 0; k < 3; ++k) { const double rr = com[k] - tkw.com_ref()[k]; qw.res[6 + k] = rr; acc += rr * rr; }
-            cost += tkw.com_w() * 0.5 * acc;
-            UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) {
-                const double w = tkw.frame_w(f);
-                acc = 0.0;
-                UNROLL_RBD for (int k = 0; k < 3; ++k) { const double rr = w != 0.0 ? qw.fx[f][k] - tkw.frame_ref(f)[k] : 0.0; qw.res[9 + 3 * f + k] = rr; acc += rr * rr; }
-                cost += w * 0.5 * acc;
-            }
-            qw.res[kRes] = 0.0;
-            qw.cost_kin = cost;
+            UNROLL_RBD for (int k = 0; k < 3; ++k) { const double rr = w != 0.0 ? qw.fx[f][k] - tkw.frame_ref(f)[k] : 0.0; qw.res[9 + 3 * f + k] = rr; acc += rr * rr; }
+            cost += w * 0.5 * acc;
         }
+        qw.res[kRes] = 0.0;
+        qw.cost_kin = cost;
     }
-    __syncthreads();
-    PSTAMP(2)
-    // ---- assembly phase: wave w owns node t0 + w
-    const int t = t0 + wave;
-    if (t >= nn) return;
-    CalcNode &q = s.nd[wave];
+}
+// (4) Gauss-Newton L_x / L_xx / L_u / L_uu / cost of node t from its LDS block, by ONE wave (all 64 lanes)
+__device__ __forceinline__ void calc_assemble(const IkBatchArgs &a, long b, int t, CalcNode &q, double *ws, const IkLayout &L, int lane,
+                                              const double *state_w0, const double *ctrl_w0, double *cost_slot) {
+    const int nn = a.T + 1;
     NodeTasks tk{a.tasks + (b * nn + t) * kNodeTaskDoubles};
     const bool terminal = t == a.T;
     const double dt = terminal ? 0.0 : a.dt[b * a.T + t];
@@ -399,8 +365,8 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a
         ws[L.Lu + (long)t * kNV + i] = sc * wu * ctrl_w[i] * q.u[i];
         ws[L.Luu + (long)t * kNV + i] = sc * wu * ctrl_w[i];
     }
-    // node costs are summed by the backward kernel: parked in the fs slot of this node
-    if (lane == 63) ws[L.fs + (long)t * kNDX] = terminal ? q.cost_kin + q.cost_sc : dt * (q.cost_kin + q.cost_sc);
+    // node costs are summed by the backward pass: parked in the gap slot of this node (multi-kernel path) / in LDS (fused kernel)
+    if (lane == 63) *cost_slot = terminal ? q.cost_kin + q.cost_sc : dt * (q.cost_kin + q.cost_sc);
     // Gauss-Newton L_x (lane j = entry j): the weighted own column of the residual Jacobian against the residuals.
     const int j = lane < kNDX ? lane : 0;
     if (lane < kNDX) {
@@ -470,6 +436,60 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a
             }
         }
     }
+}
+
+// Workgroup = two waves for TWO nodes of a problem.  Wave 0: lanes 0..17 (node A) and 32..49 (node B) each walk their
+// own part of the robot once (base lanes the base body, joint lanes their leg), the five part sums of a node meet in
+// LDS, every lane finishes its column.  Wave 1, meanwhile, fetches what ik_state_kernel left for the two nodes (a different
+// instruction stream, so it would serialise inside wave 0).  Then wave w assembles the Gauss-Newton L_x / L_xx of node w,
+// lane j = column j.  Two nodes share every instruction of the walk: the walk keeps 36 of 64 lanes busy instead of 18.
+__global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a) {
+    __shared__ CalcLds s;
+    const int nn = a.T + 1, groups = (nn + kCalcNodes - 1) / kCalcNodes;
+    const long b = slot_problem(a, blockIdx.x / groups);
+    if (b < 0) return;
+    const int t0 = (blockIdx.x % groups) * kCalcNodes, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const IkLayout L = IkLayout::make(a.T);
+    double *ws = a.ws + b * L.total;
+    if (ws[L.scal + S_DONE] != 0.0 || ws[L.scal + S_RECALC] == 0.0) return;
+#ifdef BWD_PROFILE
+    long long pc[6] = {0, 0, 0, 0, 0, 0}, pt0 = __builtin_readcyclecounter();
+#endif
+    {
+        const int *src = reinterpret_cast<const int *>(a.model);
+        int *dst = reinterpret_cast<int *>(&s.m);
+        for (int i = threadIdx.x; i < (int)(sizeof(RobotModelDev) / sizeof(int)); i += 128) dst[i] = src[i];
+    }
+    const RobotModelDev &m = s.m;
+    const double *state_w0 = batch_ptr(a.state_w, a.s_state_w, b), *ctrl_w0 = batch_ptr(a.ctrl_w, a.s_ctrl_w, b);
+    {   // states and controls of both nodes: wave w stages node w
+        const int t = t0 + wave;
+        if (t < nn) {
+            CalcNode &q = s.nd[wave];
+            if (lane < kNX) q.x[lane] = ws[L.xs + (long)t * kNX + lane];
+            if (lane < kNV) q.u[lane] = t == a.T ? 0.0 : ws[L.us + (long)t * kNV + lane];
+        }
+    }
+    __syncthreads();
+    PSTAMP(0)
+    // ---- walk phase: node index = half of the wave
+    const int hs = lane >> 5, hl = lane & 31, tw = t0 + hs;
+    const bool wvalid = tw < nn;
+    CalcNode &qw = s.nd[hs];
+    NodeTasks tkw{a.tasks + (b * nn + (wvalid ? tw : t0)) * kNodeTaskDoubles};
+    PartWalk pw;
+    double Rb[9], pb[3], Vb[6];
+    if (wave == 0 && wvalid && hl < kNV) calc_walk(m, qw, tkw, hl, Rb, pb, Vb, pw);
+    else if (wave == 1 && wvalid) calc_fetch_state(qw, ws, L, tw, hl);
+    __syncthreads();
+    PSTAMP(1)
+    if (wave == 0 && wvalid && hl < kNV) calc_columns(m, qw, tkw, hl, pw);
+    __syncthreads();
+    PSTAMP(2)
+    // ---- assembly phase: wave w owns node t0 + w
+    const int t = t0 + wave;
+    if (t >= nn) return;
+    calc_assemble(a, b, t, s.nd[wave], ws, L, lane, state_w0, ctrl_w0, ws + L.fs + (long)t * kNDX);
 #ifdef BWD_PROFILE
     PSTAMP(3)
     if (threadIdx.x == 0 && t == 0) { for (int k = 0; k < 4; ++k) ws[L.Qu + k] = (double)pc[k]; }   // the Qu slot is unused by the solver
@@ -599,14 +619,67 @@ __device__ __forceinline__ void wave_sync() {
 // them over, one node behind: the recursion hands it the factor and Y through LDS and goes on.
 __device__ __forceinline__ void bwd_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ---- control block of the fused kernel (ik_fused_kernel, below): one persistent four-wave workgroup per problem that runs
+// whole DDP iterations without leaving the chip.  Its derivative pass and Riccati pass share ONE sequence of workgroup barriers
+// ("ticks"): wave 0 runs the recursion (a node per tick), wave 1 the gains one node behind, waves 2 and 3 produce the node
+// derivatives ahead of the recursion.  Every wave executes exactly one barrier per tick whatever it has to do in it (a node, a
+// producer step, or nothing), and all of them leave the phase after the same barrier (done_flag, read right after a barrier).
+// Flags compare against `stamp` (bumped once per phase), so nothing has to be cleared.
+struct FusedCtl {
+    int ready[64];          // node t's derivatives are in the workspace (stamp)
+    int state_ready;        // ... the scalar chains of every node (state residual, Euler step: state_node) (stamp)
+    int hand_count;         // nodes (and end markers) the recursion has handed to the gains wave in this phase
+    int done_flag;          // the phase is over (stamp): set by the gains wave between two barriers
+    int stamp;
+    int abort_code;         // != 0: the tick watchdog fired (a protocol bug, never a data condition): the kernel reports and leaves
+    double node_cost[64];   // the node costs (the multi-kernel path parks them in the nodes' gap slots)
+    long long t_phase;      // telemetry: cycle count at the start of the phase, and the recursion wave's split of it
+    long long tele[4];      // [start -> first node, first node -> last node done, last node done -> the role returns, line search inside the role]
+};
+// tick watchdog: more ticks than any phase can need means a broken protocol; every wave counts the same barriers, so all of
+// them see the limit at the same tick and unwind together (no wave is left behind at a barrier)
+struct Ticker {
+    int n = 0, limit = 0;
+    bool dead = false;
+};
+// the recursion's and the gains wave's barrier: LDS traffic complete (their hand-over goes through LDS)
+__device__ __forceinline__ void tick_lds(Ticker &tk) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (++tk.n > tk.limit) tk.dead = true;
+}
+// the producers' barrier: their global stores (the node derivatives) complete as well
+__device__ __forceinline__ void tick_mem(Ticker &tk) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (++tk.n > tk.limit) tk.dead = true;
+}
+__device__ __forceinline__ int lds_flag(const int &f) { return *const_cast<const volatile int *>(&f); }
+
 // the gains wave of the two-wave backward pass
-__device__ __forceinline__ void backward_gains_wave(BackwardLds<2> &s, double *ws, double *sc, const IkLayout &L, int T, int lane) {
+template <bool FUSED>
+__device__ __forceinline__ void backward_gains_wave(BackwardLds<2> &s, double *ws, double *sc, const IkLayout &L, int T, int lane, FusedCtl *ctl,
+                                                    Ticker &tk) {
     const bool row = lane < kNDX;
     double d1 = 0.0, st = 0.0;
-    for (int k = 0;; ++k) {
-        bwd_barrier();
-        const int buf = k & 1, t = s.tnode[buf];
-        if (t < 0) break;
+    for (int k = 0;;) {
+        int t;
+        if (FUSED) {
+            tick_lds(tk);
+            if (tk.dead || lds_flag(ctl->done_flag) == ctl->stamp) return;     // (every wave leaves after this same barrier)
+            if (lds_flag(ctl->hand_count) <= k) continue;                       // a tick without a hand-over (the recursion waits for a node)
+            t = s.tnode[k & 1];
+            if (t < 0) {    // the pass is over (-1) or was given up (-2): nothing else is handed over in this phase
+                if (t == -1 && lane == kQuLane) { sc[S_D1] = d1; sc[S_STOP] = st; }
+                if (lane == 0) ctl->done_flag = ctl->stamp;
+                ++k;
+                continue;
+            }
+        } else {
+            bwd_barrier();
+            t = s.tnode[k & 1];
+            if (t < 0) break;
+        }
+        const int buf = k & 1;
+        ++k;
         if (t == T - 1) { d1 = 0.0; st = 0.0; }      // first node of a pass (a pass that failed is started again)
         double y[kNV], idg[kNV], quv[kNV];
         {
@@ -635,31 +708,41 @@ __device__ __forceinline__ void backward_gains_wave(BackwardLds<2> &s, double *w
             UNROLL_RBD for (int p = 0; p < kNV; ++p) ws[L.kff + (long)t * kNV + p] = y[p];
         }
     }
-    if (lane == kQuLane) { sc[S_D1] = d1; sc[S_STOP] = st; }
+    if (lane == kQuLane) { sc[S_D1] = d1; sc[S_STOP] = st; }      // (the multi-kernel path: after the end marker)
 }
 
-template <int NWB>
-__global__ __launch_bounds__(64 * NWB) void ik_backward_kernel(const IkBatchArgs a) {
-    __shared__ BackwardLds<NWB> s;
-    const long b = slot_problem(a, blockIdx.x);
-    if (b < 0) return;
-    const int lane = threadIdx.x & 63;
+// The recursion's wave.  FUSED: inside ik_fused_kernel -- barriers are ticks, a node waits (whole ticks) until the producer waves
+// have left its derivatives in the workspace, the total cost is summed at the end of the pass (the node costs come from LDS) and
+// the wave never returns early: it leaves with every other wave of the workgroup, after the barrier that follows done_flag.
+template <int NWB, bool FUSED>
+__device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b, BackwardLds<NWB> &s, int lane, FusedCtl *ctl, Ticker &tk) {
     const IkLayout L = IkLayout::make(a.T);
     double *ws = a.ws + b * L.total;
     double *sc = ws + L.scal;
-    if (sc[S_DONE] != 0.0) return;
     const int T = a.T;
     bool feas = sc[S_FEAS] != 0.0;
     const bool wasfeas = sc[S_WASFEAS] != 0.0;
-    if (NWB == 2 && threadIdx.x >= 64) { backward_gains_wave(reinterpret_cast<BackwardLds<2> &>(s), ws, sc, L, a.T, lane); return; }
+    const bool recalc = sc[S_RECALC] != 0.0;
     for (int i = lane; i < NWB * kPadRows * LDK; i += 64) s.Ys[0][i] = 0.0;                  // the padding of the MFMA operand image(s)
     for (int i = kNDX * LD + lane; i < kPadRows * LD + 16; i += 64) s.N[i] = 0.0;
     int hand = 0;       // NWB = 2: nodes handed to the gains wave so far (buffer = hand & 1)
+    bool gave_up = false;
+    // FUSED: node t may be read once its derivatives are there
+    auto wait_node = [&](int t) { if (FUSED) { while (lds_flag(ctl->ready[t]) != ctl->stamp && !tk.dead) tick_lds(tk); } };
+    if (FUSED) {
+        while (lds_flag(ctl->state_ready) != ctl->stamp && !tk.dead) tick_lds(tk);          // the gaps need every node's Euler step
+        wait_node(T);
+        if (tk.dead) return;        // (the watchdog: no barrier may follow; the kernel reports and leaves)
+    }
+    long long t_first = 0, t_last = 0;
+    if (FUSED) t_first = __builtin_readcyclecounter();
 
-    if (sc[S_RECALC] != 0.0) {
+    if (recalc) {
         // SolverDDP::calcDiff tail: total cost and the gaps fs
-        if (lane == 0) { double c = 0.0; for (int t = 0; t <= T; ++t) c += ws[L.fs + (long)t * kNDX]; sc[S_COST] = c; }
-        wave_sync();
+        if (!FUSED) {
+            if (lane == 0) { double c = 0.0; for (int t = 0; t <= T; ++t) c += ws[L.fs + (long)t * kNDX]; sc[S_COST] = c; }
+            wave_sync();
+        }
         if (!feas) {
             double mx = 0.0;
             if (lane <= T) {
@@ -730,16 +813,22 @@ __global__ __launch_bounds__(64 * NWB) void ik_backward_kernel(const IkBatchArgs
             o_b6 = lane < 36 ? ws[L.B6 + (long)t * 36 + lane] : 0.0;
             o_fs = row ? ws[L.fs + (long)t * kNDX + r] : 0.0;
         };
-        if (T > 0) fetch_node(T - 1, lr, lx_t, lu_t, luu_t, a6_t, b6_t, fs_t, dt);
+        bool have = false;      // node t's small reads were requested a node ahead
         for (int t = T - 1; t >= 0; --t) {
 #ifdef BWD_PROFILE
             pt0 = __builtin_readcyclecounter();
 #endif
+            if (!have) {        // the first node of a pass; in the fused kernel also a node the producers had not finished a tick ago
+                wait_node(t);
+                if (FUSED && tk.dead) return;
+                fetch_node(t, lr, lx_t, lu_t, luu_t, a6_t, b6_t, fs_t, dt);
+            }
             if (lane < 36) { s.A6[lane] = a6_t; s.B6[lane] = b6_t; }
             if (row) { s.Vx[r] = vx; s.fs[r] = fs_t; }
             const double dt_t = dt;      // (this node's; the variables above are about to be overwritten by the requests for node t - 1)
             double nlr[kNDX], nlx = 0.0, nlu = 0.0, nluu = 0.0, na6 = 0.0, nb6 = 0.0, nfs = 0.0, ndt = 0.0;
-            if (t > 0) fetch_node(t - 1, nlr, nlx, nlu, nluu, na6, nb6, nfs, ndt);
+            const bool next_there = t > 0 && (!FUSED || lds_flag(ctl->ready[t - 1]) == ctl->stamp);
+            if (next_there) fetch_node(t - 1, nlr, nlx, nlu, nluu, na6, nb6, nfs, ndt);
 #if !BWD_PREFETCH_ROW
             {    // the row itself at the top of its own node (a node ahead it costs 72 more registers: the kernel then spills and is slower)
                 const double *Lr = ws + L.Lxx + (long)t * kNDX * kNDX + (long)r * kNDX;
@@ -836,7 +925,7 @@ __global__ __launch_bounds__(64 * NWB) void ik_backward_kernel(const IkBatchArgs
                 if (row || lane == kQuLane) { UNROLL_RBD for (int p = 0; p < kNV; ++p) dst[p] = y[p]; }
                 if (urow) s.idg[buf][lane - kNDX] = mydg;
                 if (ul) s.qu[buf][uq] = qu;
-                if (lane == 0) s.tnode[buf] = t;
+                if (lane == 0) { s.tnode[buf] = t; if (FUSED) ctl->hand_count = hand + 1; }
             } else {
                 if (row) { UNROLL_RBD for (int p = 0; p < kNV; ++p) s.Ys[buf][r * LDK + p] = y[p]; }
                 improvement_and_vx();
@@ -880,7 +969,7 @@ __global__ __launch_bounds__(64 * NWB) void ik_backward_kernel(const IkBatchArgs
             }
             if (NWB == 2) {     // while the matrix pipe works through the tiles; then the node is the gains wave's
                 improvement_and_vx();
-                bwd_barrier();
+                if (FUSED) tick_lds(tk); else bwd_barrier();
                 ++hand;
             } else {
                 UNROLL_RBD for (int p = 0; p < kNV; ++p) { d1 += quv[p] * y[p]; st += quv[p] * quv[p]; }   // d1 = Qu.k, stop = |Qu|^2
@@ -925,20 +1014,22 @@ __global__ __launch_bounds__(64 * NWB) void ik_backward_kernel(const IkBatchArgs
             bad = __any(bad && (row || lane < kNV));
             wave_sync();
             PSTAMPV(8, vx)
-            if (t > 0) {     // the node requested at the top becomes the current one
+            have = next_there;
+            if (next_there) {     // the node requested at the top becomes the current one
 #if BWD_PREFETCH_ROW
                 UNROLL_RBD for (int j = 0; j < kNDX; ++j) lr[j] = nlr[j];
 #endif
                 lx_t = nlx; lu_t = nlu; luu_t = nluu; a6_t = na6; b6_t = nb6; fs_t = nfs; dt = ndt;
             }
-            if (bad) break;
+            if (bad || (FUSED && tk.dead)) break;
         }
-        if (!bad) break;
+        if (!bad || (FUSED && tk.dead)) break;
         // increaseRegularization; give up at reg_max (solve() returns false)
         xreg = fmin(xreg * 10.0, 1e9);
         if (lane == 0) { sc[S_XREG] = xreg; sc[S_RECALC] = 0.0; }
         if (xreg == 1e9) {
             if (lane == 0) { sc[S_DONE] = 1.0; sc[S_STATUS] = 2.0; atomicSub(a.active, 1); }
+            if (FUSED) { gave_up = true; break; }
             if (NWB == 2) { if (lane == 0) s.tnode[hand & 1] = -1; bwd_barrier(); }
             return;
         }
@@ -946,11 +1037,43 @@ __global__ __launch_bounds__(64 * NWB) void ik_backward_kernel(const IkBatchArgs
 #ifdef BWD_PROFILE
     if (lane == 0) { for (int k = 0; k < 9; ++k) ws[L.Quuk + k] = (double)pc[k]; }   // the Quuk slot is unused by the solver
 #endif
-    if (NWB == 2) {     // the pass is over: the gains wave writes d1 and the stopping criterion on its way out
+    if (FUSED) {
+        if (tk.dead) return;
+        t_last = __builtin_readcyclecounter();
+        // the end marker (-1: the gains wave writes d1 and the stopping criterion; -2: the pass was given up), then the total cost
+        // in SolverDDP's order from the node costs the producers left in LDS (every node has been produced by now: node 0 was
+        // waited for), then ticks until the gains wave has declared the phase over
+        if (lane == 0) { s.tnode[hand & 1] = gave_up ? -2 : -1; ctl->hand_count = hand + 1; }
+        tick_lds(tk);
+        if (tk.dead) return;
+        if (!gave_up && lane == kQuLane) sc[S_D2] = d2;
+        if (recalc && !gave_up && lane == 0) { double c = 0.0; for (int t = 0; t <= T; ++t) c += ctl->node_cost[t]; sc[S_COST] = c; }
+        for (;;) {
+            tick_lds(tk);
+            if (tk.dead || lds_flag(ctl->done_flag) == ctl->stamp) break;
+        }
+        if (lane == 0) {
+            ctl->tele[0] += t_first - ctl->t_phase; ctl->tele[1] += t_last - t_first; ctl->tele[2] += (long long)__builtin_readcyclecounter() - t_last;
+        }
+    } else if (NWB == 2) {     // the pass is over: the gains wave writes d1 and the stopping criterion on its way out
         if (lane == 0) s.tnode[hand & 1] = -1;
         bwd_barrier();
         if (lane == kQuLane) sc[S_D2] = d2;
     } else if (lane == kQuLane) { sc[S_D1] = d1; sc[S_D2] = d2; sc[S_STOP] = st; }   // the lane of the feed-forward terms
+}
+
+template <int NWB>
+__global__ __launch_bounds__(64 * NWB) void ik_backward_kernel(const IkBatchArgs a) {
+    __shared__ BackwardLds<NWB> s;
+    const long b = slot_problem(a, blockIdx.x);
+    if (b < 0) return;
+    const int lane = threadIdx.x & 63;
+    const IkLayout L = IkLayout::make(a.T);
+    double *ws = a.ws + b * L.total;
+    if (ws[L.scal + S_DONE] != 0.0) return;
+    Ticker tk;
+    if (NWB == 2 && threadIdx.x >= 64) { backward_gains_wave<false>(reinterpret_cast<BackwardLds<2> &>(s), ws, ws + L.scal, L, a.T, lane, nullptr, tk); return; }
+    backward_main_wave<NWB, false>(a, b, s, lane, nullptr, tk);
 }
 
 // ---------------------------------------------------------------------------- forward ---
@@ -1010,25 +1133,28 @@ __device__ __forceinline__ void fwd_sync() {
     else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a) {
-    __shared__ ForwardLds s;
+// FUSED (ik_fused_kernel: NW = 4, wave 3 takes no part but keeps the barriers): the problem is given, its four step lengths run
+// side by side (further rounds of four in the same call), nothing is appended to the active list, and no wave returns before
+// the last barrier.
+template <int NW, bool FUSED>
+__device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s, long b_fused) {
     const int lane = threadIdx.x & 63, wave = NW > 1 ? (int)(threadIdx.x >> 6) : 0, si = lane / kFwdLanes, l = lane % kFwdLanes;
     const bool do_chain = NW == 1 || wave == 0, do_cost = NW == 1 || wave == 1, do_reg = NW == 1 || wave == (NW == 2 ? 0 : 2);
-    const bool spec = a.fwd_spec != 0;
+    const bool spec = FUSED || a.fwd_spec != 0;
     // fwd_spec == 4: THREE workgroups per problem, workgroup g trying step lengths 2^-(4g + s): all ten in one round, on
     // separate CUs (inside one workgroup the register budget of seven waves did not allow it); the last of the
     // three to finish takes SolverDDP's decision for the problem
-    const bool all10_batch = NW == 3 && a.fwd_spec == 4;
+    const bool all10_batch = !FUSED && NW == 3 && a.fwd_spec == 4;
     // ... or for the flagged problems only (S_WIDENOW, set by the pass before): their two extra workgroups are the FIRST
     // 2 kWideMax of the grid, two per place of the wide list (first, so that they start with the first wave of workgroups
     // when the grid is larger than the chip; the unused ones return at once), the regular ones follow
-    const bool widegrid = NW > 1 && !all10_batch && a.wide != nullptr;
+    const bool widegrid = !FUSED && NW > 1 && !all10_batch && a.wide != nullptr;
     const long blk = (long)blockIdx.x - (widegrid ? 2 * kWideMax : 0);
     const bool extra = widegrid && blk < 0;
     int grp = all10_batch ? (int)(blockIdx.x % 3) : 0;
     long b;
-    if (extra) {
+    if (FUSED) b = b_fused;
+    else if (extra) {
         const int e = (int)(blockIdx.x >> 1), cur = a.iter & 1, nw = a.wcount[cur] < kWideMax ? a.wcount[cur] : kWideMax;
         b = e < nw ? (long)a.wide[cur * kWideMax + e] : -1;
         if (b >= a.B || b < -1) { index_error(a, IK_ERR_WIDE_ENTRY, (int)b); b = -1; }
@@ -1039,14 +1165,14 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
     const IkLayout L = IkLayout::make(a.T);
     double *ws = a.ws + bb * L.total;
     double *sc = ws + L.scal;
-    const bool all10 = all10_batch || (NW > 1 && spec && a.wide && pvalid && sc[S_WIDENOW] != 0.0);
+    const bool all10 = all10_batch || (!FUSED && NW > 1 && spec && a.wide && pvalid && sc[S_WIDENOW] != 0.0);
     FwdSub &q = s.sub[si];
     bool live = pvalid && sc[S_DONE] == 0.0;     // this sub-group still has a line search to do
-    if (!__any(live)) return;
+    if (!FUSED && !__any(live)) return;
     const int T = a.T, nn = a.T + 1;
     const int tslot = spec ? 4 * grp + si : 0;       // where this sub-group's trial trajectory goes
     const long xs_try = L.xs_try + (long)tslot * nn * kNX, us_try = L.us_try + (long)tslot * T * kNV;
-    {   // the robot model is read many times per node: stage it in LDS once
+    if (!FUSED) {   // the robot model is read many times per node: stage it in LDS once (the fused kernel did, when it started)
         const int *src = reinterpret_cast<const int *>(a.model);
         int *dst = reinterpret_cast<int *>(&s.m);
         for (int i = threadIdx.x; i < (int)(sizeof(RobotModelDev) / sizeof(int)); i += 64 * NW) dst[i] = src[i];
@@ -1315,7 +1441,8 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
     if (pvalid && lane == 0) { ws[L.Qu + 8 + 2 * wave] = (double)fwork; ws[L.Qu + 9 + 2 * wave] = (double)fwait; }   // tools/bwd_profile.py
     if (pvalid && lane == 0 && wave == 0) { for (int k = 0; k < 5; ++k) ws[L.Qu + 16 + k] = (double)fph[k]; }
 #endif
-    if (!owner || !do_chain) return;
+    if (!FUSED && (!owner || !do_chain)) return;
+    if (owner && do_chain) {
     double xreg = sc[S_XREG];
     if (accepted) {   // setCandidate(xs_try, us_try, true)
         const long xsrc = L.xs_try + (long)win * nn * kNX, usrc = L.us_try + (long)win * T * kNV;
@@ -1339,7 +1466,7 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
         if (accepted) { sc[S_WASFEAS] = feas ? 1.0 : 0.0; sc[S_FEAS] = 1.0; sc[S_COST] = cost_try; sc[S_RECALC] = 1.0; }
         else sc[S_RECALC] = 0.0;
         sc[S_XREG] = xreg; sc[S_ITERS] = iters;
-        if (!done && a.list) {      // goes on: onto the next iteration's list (the order there is arbitrary; nothing depends on it)
+        if (!done && a.list && !FUSED) {      // goes on: onto the next iteration's list (the order there is arbitrary; nothing depends on it)
             const int nxt = (a.iter + 1) & 1;
             const int pos = atomicAdd(a.count + nxt, 1);
             if ((unsigned)pos < (unsigned)a.B) a.list[(long)nxt * a.B + pos] = (int)b;
@@ -1351,12 +1478,278 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
                 if (at < kWideMax) { a.wide[nxt * kWideMax + at] = (int)b; now = 1.0; }
             }
             sc[S_WIDENOW] = now;
-        }
+            if (a.near && sc[S_STOP] < a.near_stop) atomicAdd(a.near + nxt, 1);       // express-lane trigger statistics (ik_select_kernel)
+        } else if (FUSED && !done && widen) sc[S_WIDE] = 1.0;
         if (iters <= (double)kTraceIters) {
             double *tr = ws + L.trace + ((long)iters - 1) * kTraceDoubles;
             tr[0] = accepted ? cost_try : cost; tr[1] = xreg; tr[2] = accepted ? alpha : 0.0; tr[3] = sc[S_STOP];
         }
         if (done) { sc[S_DONE] = 1.0; sc[S_STATUS] = status; atomicSub(a.active, 1); }
+    }
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a) {
+    __shared__ ForwardLds s;
+    forward_body<NW, false>(a, s, -1);
+}
+
+// ------------------------------------------------------------------------------ fused ---
+// One persistent workgroup of four waves (one per SIMD of a CU) runs whole DDP iterations of ONE problem without leaving the chip
+// and without the host: derivative pass and Riccati pass pipelined over a common sequence of barriers (FusedCtl above), then the
+// line search.  Same device code as the multi-kernel path (state_node, calc_*, backward_*_wave, forward_body), so a problem's
+// result does not depend on which path -- or which mixture of the two -- solved it.  Used for (a) the EXPRESS LANE: the problems
+// ik_select_kernel picks as stragglers-to-be leave the batch early and iterate here at their own pace, on a side stream, while
+// the batch goes on in lock-step without them; (b) the tail: once few problems are left, all of them.
+struct alignas(16) FusedLds {
+    BackwardLds<2> bw;
+    ForwardLds fw;              // fw.m: the robot model, staged once (the producers read it too)
+    CalcNode nd[2][kCalcNodes]; // the two nodes each producer wave has in hand
+    FusedCtl ctl;
+    IkBatchArgs args;           // the launch arguments, for the role functions (below)
+};
+// File scope, so that the role functions below can name it (an LDS object reached through a generic reference would be read with
+// flat instructions).  Only ik_fused_kernel uses it.
+__shared__ FusedLds g_fused;
+
+// The four roles are separate NON-INLINED functions: in one function body hipcc's register allocator lets the roles' big register
+// arrays interfere (the Riccati wave's matrix rows, the producers' robot walk, the line search): 301 spilled registers for code
+// that spills none (Riccati pass) to 124 (line search) as kernels of their own, and every phase ran 35-65 % slower than its
+// kernel.  As functions each role has its own allocation.  They take no pointers: the launch arguments come out of LDS, every
+// field made wave-uniform again (v_readfirstlane: scalar registers, scalar branches, as kernel arguments are).
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long uni(long v) {
+    return (long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)v >> 32)) << 32) |
+                  (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)v));
+}
+template <class P> __device__ __forceinline__ P *uni(P *p) { return reinterpret_cast<P *>(uni((long)p)); }
+__device__ __forceinline__ IkBatchArgs fused_args() {
+    const IkBatchArgs &g = g_fused.args;
+    IkBatchArgs a;
+    a.B = uni(g.B); a.T = uni(g.T); a.maxiter = uni(g.maxiter); a.fwd_spec = uni(g.fwd_spec); a.bwd_waves = uni(g.bwd_waves);
+    a.list = uni(g.list); a.count = uni(g.count); a.wide = uni(g.wide); a.wcount = uni(g.wcount); a.err = uni(g.err); a.near = uni(g.near);
+    a.xmeta = uni(g.xmeta); a.xlist = uni(g.xlist); a.iter = uni(g.iter); a.n_launch = uni(g.n_launch);
+    a.model = uni(g.model); a.x0 = uni(g.x0); a.dt = uni(g.dt); a.tasks = uni(g.tasks); a.state_w = uni(g.state_w); a.x_reg = uni(g.x_reg);
+    a.ctrl_w = uni(g.ctrl_w); a.s_state_w = uni(g.s_state_w); a.s_ctrl_w = uni(g.s_ctrl_w); a.s_x_reg = uni(g.s_x_reg);
+    a.sn_state_w = uni(g.sn_state_w); a.sn_x_reg = uni(g.sn_x_reg); a.sn_ctrl_w = uni(g.sn_ctrl_w); a.ws = uni(g.ws); a.active = uni(g.active); a.near_stop = g.near_stop;
+    return a;
+}
+
+// Producer wave p (0 / 1) of the fused kernel: node pairs p, p + 2, ... counted from the terminal node down (pair j = nodes
+// T - 2j, T - 2j - 1), two ticks per pair -- [stage, walk, columns] [state terms in, assemble A, assemble B] -- so the two of them
+// deliver two nodes per tick against the recursion's one; producer 1 spends its first tick on the scalar chains of every node
+// (one lane per node).  Walk and columns share a tick because the walk's per-lane state must reach the columns in REGISTERS, as it
+// does in ik_calcdiff_kernel: parked in LDS in between (tried: shorter ticks) the compiler can no longer contract a product of
+// the walk into a sum of the columns, and the node derivatives differ in their last bits from the multi-kernel path's; carried in
+// registers around the loop's barrier hipcc spills it.
+__device__ __forceinline__ void producer_wave(const IkBatchArgs &a, long b, FusedLds &s, int p, int lane, Ticker &tk) {
+    FusedCtl &ctl = s.ctl;
+    const int stamp = ctl.stamp, T = a.T, nn = T + 1, npairs = (nn + 1) / 2;
+    const IkLayout L = IkLayout::make(T);
+    double *ws = a.ws + b * L.total;
+    const bool recalc = ws[L.scal + S_RECALC] != 0.0;
+    const RobotModelDev &m = s.fw.m;
+    const double *state_w0 = batch_ptr(a.state_w, a.s_state_w, b), *ctrl_w0 = batch_ptr(a.ctrl_w, a.s_ctrl_w, b);
+    const int hs = lane >> 5, hl = lane & 31;
+    CalcNode &qw = s.nd[p][hs];
+    int pair = p, phase = p == 1 ? 0 : 1;
+    bool first = true;
+    for (;;) {
+        if (!recalc) {
+            // the line search of the iteration before accepted nothing: the derivatives in the workspace are still those of this trajectory
+            if (first && p == 0) { if (lane <= T) ctl.ready[lane] = stamp; if (lane == 0) ctl.state_ready = stamp; }
+        } else if (phase == 0) {
+            if (lane <= T) state_node(a, b, lane, ws, L);
+            if (lane == 0) ctl.state_ready = stamp;
+            phase = 1;
+        } else if (pair < npairs) {
+            const int tA = T - 2 * pair, tB = tA - 1, tw = hs == 0 ? tA : tB;
+            const bool wvalid = tw >= 0;
+            if (phase == 1) {
+                UNROLL_RBD for (int h = 0; h < kCalcNodes; ++h) {
+                    const int t = h == 0 ? tA : tB;
+                    if (t >= 0) {
+                        CalcNode &q = s.nd[p][h];
+                        if (lane < kNX) q.x[lane] = ws[L.xs + (long)t * kNX + lane];
+                        if (lane < kNV) q.u[lane] = t == T ? 0.0 : ws[L.us + (long)t * kNV + lane];
+                    }
+                }
+                wave_sync();
+                NodeTasks tkw{a.tasks + (b * nn + (wvalid ? tw : tA)) * kNodeTaskDoubles};
+                PartWalk pw;
+                double Rb[9], pb[3], Vb[6];
+                if (wvalid && hl < kNV) calc_walk(m, qw, tkw, hl, Rb, pb, Vb, pw);
+                wave_sync();
+                if (wvalid && hl < kNV) calc_columns(m, qw, tkw, hl, pw);
+                phase = 2;
+            } else {
+                // (the scalar chains of these nodes are there: they take producer 1's first tick, and this is tick 2 at the earliest)
+                if (wvalid) calc_fetch_state(qw, ws, L, tw, hl);
+                wave_sync();
+                calc_assemble(a, b, tA, s.nd[p][0], ws, L, lane, state_w0, ctrl_w0, &ctl.node_cost[tA]);
+                if (tB >= 0) calc_assemble(a, b, tB, s.nd[p][1], ws, L, lane, state_w0, ctrl_w0, &ctl.node_cost[tB]);
+                if (lane == 0) { ctl.ready[tA] = stamp; if (tB >= 0) ctl.ready[tB] = stamp; }
+                phase = 1; pair += 2;
+            }
+        }
+        first = false;
+        tick_mem(tk);
+        if (tk.dead || lds_flag(ctl.done_flag) == stamp) return;
+    }
+}
+
+// the roles: each returns the ticks it counted, or -1 when the watchdog fired (every wave counts the same barriers)
+__device__ __noinline__ int fused_role_recursion(long b_, int limit) {
+    const IkBatchArgs a = fused_args();
+    Ticker tk; tk.limit = uni(limit);
+    backward_main_wave<2, true>(a, uni(b_), g_fused.bw, (int)(threadIdx.x & 63), &g_fused.ctl, tk);
+    return tk.dead ? -1 : tk.n;
+}
+__device__ __noinline__ int fused_role_gains(long b_, int limit) {
+    const IkBatchArgs a = fused_args();
+    const IkLayout L = IkLayout::make(a.T);
+    double *ws = a.ws + uni(b_) * L.total;
+    Ticker tk; tk.limit = uni(limit);
+    backward_gains_wave<true>(g_fused.bw, ws, ws + L.scal, L, a.T, (int)(threadIdx.x & 63), &g_fused.ctl, tk);
+    return tk.dead ? -1 : tk.n;
+}
+__device__ __noinline__ int fused_role_producer(long b_, int limit) {
+    const IkBatchArgs a = fused_args();
+    Ticker tk; tk.limit = uni(limit);
+    producer_wave(a, uni(b_), g_fused, uni((int)(threadIdx.x >> 6)) - 2, (int)(threadIdx.x & 63), tk);
+    return tk.dead ? -1 : tk.n;
+}
+__device__ __noinline__ void fused_role_line_search(long b_) {
+    const long long t0 = __builtin_readcyclecounter();
+    const IkBatchArgs a = fused_args();
+    forward_body<4, true>(a, g_fused.fw, uni(b_));
+    if (threadIdx.x == 0) g_fused.ctl.tele[3] += (long long)__builtin_readcyclecounter() - t0;
+}
+
+// plist[0 .. *pcount) (at most gridDim.x of them): the problems to run to the end.  gate: when given, the launch is void
+// unless gate[0] == 1 and gate[2] == gate_iter (the express lane: ik_select_kernel decides on the device whether, and when,
+// it starts; the host enqueues the pair after every early iteration).
+__global__ __launch_bounds__(256) void ik_fused_kernel(const IkBatchArgs a, const int *plist, const int *pcount, const int *gate, int gate_iter) {
+    FusedLds &s = g_fused;
+    if (gate && (gate[0] != 1 || gate[2] != gate_iter)) return;
+    const int n = *pcount;
+    if ((int)blockIdx.x >= n) return;
+    const int bi = plist[blockIdx.x];
+    if ((unsigned)bi >= (unsigned)a.B) { if (threadIdx.x == 0) index_error(a, IK_ERR_LIST_ENTRY, bi); return; }
+    const long b = bi;
+    const int wave = threadIdx.x >> 6;
+    const IkLayout L = IkLayout::make(a.T);
+    double *ws = a.ws + b * L.total;
+    double *sc = ws + L.scal;
+    {
+        const int *src = reinterpret_cast<const int *>(a.model);
+        int *dst = reinterpret_cast<int *>(&s.fw.m);
+        for (int i = threadIdx.x; i < (int)(sizeof(RobotModelDev) / sizeof(int)); i += 256) dst[i] = src[i];
+    }
+    if (threadIdx.x < 64) s.ctl.ready[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { s.ctl.state_ready = 0; s.ctl.hand_count = 0; s.ctl.done_flag = 0; s.ctl.stamp = 0; s.ctl.abort_code = 0; s.args = a;
+                            for (int k = 0; k < 4; ++k) s.ctl.tele[k] = 0; }
+    __syncthreads();
+    const int limit = 24 * (a.T + 8);      // a pass takes T + ~6 ticks; the regularisation can restart it 18 times (1e-9 ... 1e9)
+    long long cyc_a = 0, cyc_b = 0, ticks = 0, turns = 0;       // telemetry (tools/ik_run.py): cycles in the two phases, ticks, iterations
+    for (int turn = 0; turn <= a.maxiter; ++turn) {      // one DDP iteration per turn (the forward pass ends the problem at maxiter)
+        if (sc[S_DONE] != 0.0) break;
+        const long long c0 = __builtin_readcyclecounter();
+        if (threadIdx.x == 0) { s.ctl.stamp += 1; s.ctl.hand_count = 0; s.ctl.t_phase = c0; }
+        __syncthreads();
+        const int nt = wave == 0 ? fused_role_recursion(b, limit) : wave == 1 ? fused_role_gains(b, limit) : fused_role_producer(b, limit);
+        if (nt < 0) {      // every wave has counted the same barriers: all of them are here, none waits at one
+            if (threadIdx.x == 0) index_error(a, IK_ERR_FUSED_WATCHDOG, (int)b);
+            return;
+        }
+        __syncthreads();
+        const long long c1 = __builtin_readcyclecounter();
+        cyc_a += c1 - c0; ticks += nt; ++turns;
+        if (sc[S_DONE] != 0.0) break;       // the pass was given up at the regularisation's ceiling
+        fused_role_line_search(b);
+        __syncthreads();
+        cyc_b += __builtin_readcyclecounter() - c1;
+    }
+    if (threadIdx.x == 0) {     // (the Qu slot of the workspace is unused by the solver)
+        ws[L.Qu + 0] = (double)cyc_a; ws[L.Qu + 1] = (double)cyc_b; ws[L.Qu + 2] = (double)ticks; ws[L.Qu + 3] = (double)turns;
+        for (int k = 0; k < 4; ++k) ws[L.Qu + 4 + k] = (double)s.ctl.tele[k];
+    }
+}
+
+// The express lane's selection, one workgroup, in front of iteration a.iter.  It acts ONCE per batch solve, at the first call
+// that finds the batch where the lane pays: (almost) nobody has finished yet, at least half of the problems are within reach of
+// the stopping threshold (|Q_u|^2 < near_stop at their last Riccati pass) and an iteration earlier (almost) none was -- the batch
+// crossed that line in ONE iteration: it converges fast, it will be gone in two or three iterations, and what is far from
+// converging now will still be iterating long after.  (Measured on the CPU twin's traces: in the Solo12 H_ik = 10 batch the median
+// |Q_u|^2 falls 21 -> 0.07 -> 1e-4 over iterations 2, 3, 4, and after iteration 3 the 24 longest-running problems, 12 ... 36
+// iterations, are all among the 110 largest |Q_u|^2; the synthetic Go2 H_ik = 30 batch converges slowly everywhere, the share of
+// problems below the line creeps up over ten iterations, |Q_u|^2 does not rank its long runs -- and the lane stays shut.)  The
+// `cap` problems with the largest |Q_u|^2 move from the active list to xlist; the fused kernel enqueued behind this one on the
+// side stream takes them.  xmeta = {state (1: taken), count, iteration, -}.
+__global__ __launch_bounds__(1024) void ik_select_kernel(const IkBatchArgs a, int cap) {
+    __shared__ unsigned hist[16];
+    __shared__ unsigned long long prefix_s;
+    __shared__ int want_s, nx_s, nk_s, go_s;
+    const int cur = a.iter & 1, tid = threadIdx.x;
+    const IkLayout L = IkLayout::make(a.T);
+    if (tid == 0) {
+        const int n = a.count[cur];
+        int c = cap < kExpressMax ? cap : kExpressMax;
+        if (c > n / 8) c = n / 8;          // never more than an eighth of what is left
+        go_s = a.xmeta[0] == 0 && c > 0 && (unsigned)n <= (unsigned)a.B && (long)n * 50 >= (long)a.B * 49 && (long)a.near[cur] * 2 >= (long)a.B &&
+               (long)a.near[cur ^ 1] * 20 <= (long)a.B;     // (near[cur ^ 1]: the iteration before; this iteration's state kernel resets it)
+        want_s = c; prefix_s = 0ull; nx_s = 0; nk_s = 0;
+    }
+    __syncthreads();
+    if (!go_s) return;
+    const int n = a.count[cur], want = want_s;
+    const int *lst = a.list + (long)cur * a.B;
+    int *other = a.list + (long)(cur ^ 1) * a.B;       // free until this iteration's forward pass appends to it
+    auto key_of = [&](int i) -> unsigned long long {   // |Q_u|^2 >= 0: the bit pattern orders like the value (NaN above everything)
+        const int p = lst[i];
+        const double v = (unsigned)p < (unsigned)a.B ? a.ws[(long)p * L.total + L.scal + S_STOP] : 0.0;
+        return (unsigned long long)__double_as_longlong(v < 0.0 ? 0.0 : v);
+    };
+    // radix select, four bits at a time from the top: prefix = the want-th largest key
+    int remaining = want;
+    for (int shift = 60; shift >= 0; shift -= 4) {
+        if (tid < 16) hist[tid] = 0u;
+        __syncthreads();
+        const unsigned long long pre = prefix_s, mask = shift == 60 ? 0ull : (~0ull << (shift + 4));
+        for (int i = tid; i < n; i += 1024) {
+            const unsigned long long k = key_of(i);
+            if ((k & mask) == pre) atomicAdd(&hist[(k >> shift) & 15u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int d = 15, acc = 0;
+            for (; d > 0; --d) { if (acc + (int)hist[d] >= remaining) break; acc += (int)hist[d]; }
+            remaining -= acc;
+            prefix_s = pre | ((unsigned long long)d << shift);
+            want_s = remaining;      // of the keys equal to the final prefix, this many are taken
+        }
+        __syncthreads();
+        remaining = want_s;
+    }
+    const unsigned long long kth = prefix_s;
+    // above the threshold: taken; equal to it: the first `remaining` to arrive; the rest stays on the list
+    for (int i = tid; i < n; i += 1024) {
+        const unsigned long long k = key_of(i);
+        const int p = lst[i];
+        bool take = k > kth;
+        if (!take && k == kth) take = atomicAdd(&nk_s, 1) < remaining;
+        if (take) { const int at = atomicAdd(&nx_s, 1); if (at < kExpressMax) a.xlist[at] = p; else take = false; }
+        if (!take) other[atomicAdd(&go_s, 1) - 1] = p;         // go_s was 1: it now counts the kept ones + 1
+    }
+    __syncthreads();
+    const int kept = go_s - 1;
+    for (int i = tid; i < kept; i += 1024) const_cast<int *>(lst)[i] = other[i];
+    if (tid == 0) {
+        a.count[cur] = kept;
+        a.xmeta[1] = nx_s < kExpressMax ? nx_s : kExpressMax; a.xmeta[2] = a.iter;
+        __threadfence();
+        a.xmeta[0] = 1;
     }
 }
 
@@ -1404,8 +1797,10 @@ __global__ void ik_state_ops_selftest_kernel(const double *x0, const double *x1,
 
 // the active-problem counter, copied to a host-mapped word: the host reads it after its stream synchronisation
 // without a device-to-host copy operation (a 4-byte hipMemcpy into pageable memory costs ~50 us per DDP iteration)
-__global__ void ik_publish_active_kernel(const int *active, const int *err, volatile int *host_word) {
+__global__ void ik_publish_active_kernel(const int *active, const int *err, const int *count_next, const int *xmeta, volatile int *host_word) {
     host_word[1] = err ? err[0] : 0;
+    host_word[2] = count_next ? *count_next : -1;       // problems on the list the next iteration runs over (the express lane's are not)
+    host_word[3] = xmeta ? xmeta[0] : 0;                // the express lane has taken its problems
     host_word[0] = *active;
     __threadfence_system();
 }
@@ -1438,8 +1833,8 @@ hipError_t ik_launch_state_ops_selftest(const double *x0, const double *x1, cons
     hipLaunchKernelGGL(ik_state_ops_selftest_kernel, dim3((n + 63) / 64), dim3(64), 0, st, x0, x1, dx, n, dq, dr, iq, ir);
     return hipGetLastError();
 }
-hipError_t ik_launch_publish_active(const int *active, const int *err, int *host_word_dev, hipStream_t st) {
-    hipLaunchKernelGGL(ik_publish_active_kernel, dim3(1), dim3(1), 0, st, active, err, host_word_dev);
+hipError_t ik_launch_publish_active(const IkBatchArgs &a, int next_iter, int *host_word_dev, hipStream_t st) {
+    hipLaunchKernelGGL(ik_publish_active_kernel, dim3(1), dim3(1), 0, st, a.active, a.err, a.count ? a.count + (next_iter & 1) : nullptr, a.xmeta, host_word_dev);
     return hipGetLastError();
 }
 hipError_t ik_launch_init(const IkBatchArgs &a, hipStream_t st) {
@@ -1469,6 +1864,21 @@ hipError_t ik_launch_forward(const IkBatchArgs &a, hipStream_t st) {
     else if (a.fwd_spec == 3) hipLaunchKernelGGL(ik_forward_kernel<3>, dim3(n + (a.wide ? 2 * kWideMax : 0)), dim3(192), 0, st, a);
     else if (a.fwd_spec) hipLaunchKernelGGL(ik_forward_kernel<2>, dim3(n + (a.wide ? 2 * kWideMax : 0)), dim3(128), 0, st, a);
     else hipLaunchKernelGGL(ik_forward_kernel<1>, dim3((n + 3) / 4), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+// the express lane (a.iter = the iteration about to start): selection on `st`, the fused kernel for what it took on `side`
+hipError_t ik_launch_select(const IkBatchArgs &a, int cap, hipStream_t st) {
+    hipLaunchKernelGGL(ik_select_kernel, dim3(1), dim3(1024), 0, st, a, cap);
+    return hipGetLastError();
+}
+hipError_t ik_launch_fused_express(const IkBatchArgs &a, int cap, hipStream_t side) {
+    hipLaunchKernelGGL(ik_fused_kernel, dim3((unsigned)(cap < kExpressMax ? cap : kExpressMax)), dim3(256), 0, side, a, a.xlist, a.xmeta + 1, a.xmeta, a.iter);
+    return hipGetLastError();
+}
+// the tail: every problem still on the active list of iteration a.iter (at most a.n_launch of them) to the end
+hipError_t ik_launch_fused_tail(const IkBatchArgs &a, hipStream_t st) {
+    hipLaunchKernelGGL(ik_fused_kernel, dim3((unsigned)launch_problems(a)), dim3(256), 0, st, a, a.list + (long)(a.iter & 1) * a.B, a.count + (a.iter & 1),
+                       static_cast<const int *>(nullptr), 0);
     return hipGetLastError();
 }
 hipError_t ik_launch_centroidal_state(const RobotModelDev *model, const double *x, double *out9, int B, hipStream_t st) {

@@ -79,12 +79,16 @@ enum IkScal { S_COST = 0, S_XREG, S_D1, S_D2, S_STOP, S_FEAS, S_WASFEAS, S_DONE,
 // problems cause a second round in 76 of the 100 iterations), and a second round costs the whole batch a rollout's latency.
 // Such a problem is flagged (S_WIDE) and from then on gets all ten step lengths at once, on three workgroups.
 constexpr int kWideMax = 32;
-// ints of device scratch behind bmpc_ik_batch_t.active_list: list[2][B], count[2], wide_count[2], wide[2][kWideMax], err[2]
-inline long active_list_ints(long B) { return 2 * B + 4 + 2 * kWideMax + 2; }
+// The express lane (ik_select_kernel / ik_fused_kernel in ik_ddp.hip): at most this many problems leave the batch early
+constexpr int kExpressMax = 256;
+// ints of device scratch behind bmpc_ik_batch_t.active_list: list[2][B], count[2], wide_count[2], wide[2][kWideMax], err[2],
+// near[2], xmeta[4], xlist[kExpressMax]
+inline long active_list_ints(long B) { return 2 * B + 4 + 2 * kWideMax + 2 + 2 + 4 + kExpressMax; }
 // Index checks of the list code (always on: a few scalar compares per workgroup).  A list entry, a list length or an append
 // position outside its range is never used as an index: the kernel records the code in err[0] (first one wins), drops the
 // access, and the DDP loop returns BMPC_DEVICE_ERROR with it instead of the process dying in a memory fault.
-enum IkIndexError { IK_ERR_NONE = 0, IK_ERR_LIST_ENTRY = 1, IK_ERR_LIST_COUNT = 2, IK_ERR_LIST_APPEND = 3, IK_ERR_WIDE_ENTRY = 4 };
+enum IkIndexError { IK_ERR_NONE = 0, IK_ERR_LIST_ENTRY = 1, IK_ERR_LIST_COUNT = 2, IK_ERR_LIST_APPEND = 3, IK_ERR_WIDE_ENTRY = 4,
+                    IK_ERR_FUSED_WATCHDOG = 5 };   // the fused kernel's tick watchdog (a protocol bug, never a data condition)
 
 struct IkBatchArgs {
     int B, T, maxiter;
@@ -98,6 +102,9 @@ struct IkBatchArgs {
     int *list, *count;
     int *wide, *wcount;        // the flagged problems among them (see kWideMax): wide[k & 1][0 .. min(wcount[k & 1], kWideMax))
     int *err;                  // [2] index-check record of the list code (IkIndexError, offending value), or null without a list
+    int *near;                 // [2] per list: problems whose last |Q_u|^2 was below kNearStop (the express lane's trigger statistics)
+    int *xmeta, *xlist;        // the express lane: {taken, count, iteration, -} and the problems it took
+    double near_stop;          // |Q_u|^2 below this counts as "within reach of the stopping threshold" in the lane's trigger statistics
     int iter, n_launch;
     const RobotModelDev *model;
     const double *x0;          // [B][37]
@@ -118,8 +125,12 @@ hipError_t ik_launch_state(const IkBatchArgs &a, hipStream_t s);      // before 
 hipError_t ik_launch_calcdiff(const IkBatchArgs &a, hipStream_t s);
 hipError_t ik_launch_backward(const IkBatchArgs &a, hipStream_t s);
 hipError_t ik_launch_forward(const IkBatchArgs &a, hipStream_t s);
-// host_word_dev[0] = *active, host_word_dev[1] = err ? err[0] : 0   (device alias of two host-mapped ints)
-hipError_t ik_launch_publish_active(const int *active, const int *err, int *host_word_dev, hipStream_t s);
+// host_word_dev[0..3] = *active, index-check code, length of the list iteration next_iter runs over, express lane taken
+// (device alias of four host-mapped ints)
+hipError_t ik_launch_publish_active(const IkBatchArgs &a, int next_iter, int *host_word_dev, hipStream_t s);
+hipError_t ik_launch_select(const IkBatchArgs &a, int cap, hipStream_t s);
+hipError_t ik_launch_fused_express(const IkBatchArgs &a, int cap, hipStream_t side);
+hipError_t ik_launch_fused_tail(const IkBatchArgs &a, hipStream_t s);
 // centroidal state [com, vcom, L] (9) of (q, v): KinoDynMP::optimize's x0 (kino_dyn.cpp:42,86-97)
 hipError_t ik_launch_centroidal_state(const RobotModelDev *model, const double *x, double *out9, int B, hipStream_t s);
 // com (3) and h_g (6) along a state trajectory [B][n][37]  (InverseKinematics::return_opt_com/mom)

@@ -61,7 +61,7 @@ class KinoDynDeviceBatch:
     def set_schedule(self, **fields):
         """per-batch scheduling thresholds of the DDP loop (bmpc_ik_sched_t)"""
         for k, v in fields.items():
-            if k not in ("spec_below", "all_steps_below", "gains_wave_below", "debug_inject"):
+            if k not in ("spec_below", "all_steps_below", "gains_wave_below", "express_cap", "debug_inject"):
                 raise KeyError(k)
             setattr(self.desc.ik.sched, k, int(v))
 
@@ -92,6 +92,9 @@ class KinoDynDeviceBatch:
         out["ik_iters"], out["ik_status"] = sc[:, 8].astype(np.int64), sc[:, 10].astype(np.int64)
         out["ik_wide_line_search"] = sc[:, 12] != 0     # flagged: ran its later line searches with all ten step lengths at once
         out["ddp_loop_iters"] = self.iters_run.value
+        # DDP iterations a problem ran inside the persistent fused kernel (the express lane); 0 = solved by the batch's own kernels
+        oq = o["k"] + T * 18
+        out["ik_fused_iters"] = ws[:, oq + 3].astype(np.int64) if T * 18 >= 8 else np.zeros(ws.shape[0], dtype=np.int64)
         # rows [iteration][cost, regularisation, accepted step length (0 = none), |Q_u|^2]; rows past ik_iters are stale
         out["ik_trace"] = ws[:, self.trace_off:self.trace_off + self.trace_iters * self.trace_width].reshape(-1, self.trace_iters, self.trace_width)
         return out

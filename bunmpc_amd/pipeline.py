@@ -13,7 +13,8 @@ DEFAULT_STREAMS = 3
 # The batched DDP gives every problem a second wave for the Riccati gains once few problems are left: that shortens ONE
 # batch's tail by using SIMDs that idle -- with several batches in flight they do not idle, the other batches use them
 # (measured, Go2 H = 60, three batches: 2.02e4 solves/s without, 1.97e4 at a third of the threshold, 1.90e4 with).
-IN_FLIGHT_SCHEDULE = {"gains_wave_below": -1}
+# ... and the express lane (a persistent kernel on a side stream per batch) is for a batch that has the chip to itself
+IN_FLIGHT_SCHEDULE = {"gains_wave_below": -1, "express_cap": -1}
 
 
 class StreamPool:

@@ -220,6 +220,8 @@ typedef struct {
     int spec_below;         /* four step lengths of a problem side by side (bmpc_ik_set_speculative_below) */
     int all_steps_below;    /* all ten step lengths at once on three workgroups (bmpc_ik_set_all_steps) */
     int gains_wave_below;   /* a second wave per problem for the Riccati gains (bmpc_ik_set_gains_wave_below) */
+    int express_cap;        /* NOT a threshold: the most problems the express lane may take off the batch (bmpc_ik_set_express_capacity;
+                               0 = the process default, < 0 = no express lane) */
     int debug_inject;       /* tests only: 1 = overwrite the first active-list entry with an out-of-range index right after the
                                list is initialised; the solve must then return BMPC_DEVICE_ERROR (index checks of the list code) */
 } bmpc_ik_sched_t;
@@ -258,6 +260,18 @@ int bmpc_ik_set_gains_wave_below(int n_active);
 /* Host waits of the DDP loop (no effect on results): 1 (default) = the waiting host thread sleeps until the device's interrupt
  * (hipEventBlockingSync), 0 = it spins.  Returns the old value. */
 int bmpc_ik_set_blocking_waits(int on);
+/* The express lane (needs bmpc_ik_batch_t.active_list; no effect on results).  A batch that converges fast leaves a thin tail of
+ * problems iterating long after the rest has finished, and in lock-step those pay every early iteration at the whole batch's pace.
+ * In front of iterations 2..12 a one-workgroup kernel looks at the batch and, ONCE -- when (almost) nobody has finished yet, at
+ * least half of the problems are near the stopping threshold and an iteration earlier (almost) none was -- takes the n problems
+ * farthest from it (never more than an eighth of the batch) off the active list; a persistent fused kernel (one four-wave
+ * workgroup per problem: derivative pass, Riccati pass and line search of whole DDP iterations without leaving the chip, no
+ * host look) runs them to the end on a side stream while the batch goes on without them.  Default 96; 0 = no express lane.
+ * Returns the old value. */
+int bmpc_ik_set_express_capacity(int n);
+/* ... and what "near the stopping threshold" means in that trigger: |Q_u|^2 < stop at the problem's last Riccati pass (SolverDDP
+ * stops below 1e-9).  Default 1.0.  Returns the old value. */
+double bmpc_ik_set_express_near(double stop);
 int bmpc_ik_solve_batch_device(const bmpc_ik_batch_t *d, void *hip_stream);
 /* Measurement aid (additive): with profiling on, the DDP loop brackets each of its kernels with events; after a batch solve
  * bmpc_ik_last_profile returns the summed milliseconds of ik_state / ik_calcdiff / ik_backward / ik_forward and of the rest

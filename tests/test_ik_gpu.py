@@ -400,3 +400,34 @@ def test_list_index_checks_report_instead_of_faulting(model):
     kb.solve()
     again = kb.results()
     assert np.array_equal(again["xs"], good["xs"]) and np.array_equal(again["ik_iters"], good["ik_iters"])
+
+
+def test_express_lane_does_not_change_results(model):
+    """The express lane (ik_select_kernel + the persistent fused kernel on a side stream): on the Solo12 batch it takes the problems
+    farthest from converging off the active list after three iterations and runs them to the end in one launch.  Same device
+    code as the multi-kernel path, so every bit of every problem's result must be the same with the lane and without it --
+    for the problems the lane took and for those it left."""
+    from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
+    wb = problems.make_wb_batch(model, 1024)
+    out = {}
+    for name, cap in (("off", -1), ("on", 96)):
+        kb = KinoDynDeviceBatch(wb, model, num_iters=10, schedule={"express_cap": cap})
+        kb.solve()
+        out[name] = kb.results()
+        kb.solve()                                   # a second solve of the same objects: the lane's device state starts afresh
+        again = kb.results()
+        assert np.array_equal(again["xs"], out[name]["xs"]) and np.array_equal(again["ik_fused_iters"], out[name]["ik_fused_iters"])
+    off, on = out["off"], out["on"]
+    took = on["ik_fused_iters"] > 0
+    print("express lane: took %d of 1024 problems (DDP iterations of those: %s...), host loop %d -> %d iterations"
+          % (took.sum(), sorted(on["ik_iters"][took].tolist())[-5:], off["ddp_loop_iters"], on["ddp_loop_iters"]))
+    assert not np.any(off["ik_fused_iters"]) and 16 <= took.sum() <= 96
+    longest = np.argsort(-on["ik_iters"])[:8]
+    assert np.all(took[longest])                     # what it is for: the longest-running problems are on the lane
+    assert on["ddp_loop_iters"] < off["ddp_loop_iters"]
+    for k in ("xs", "us", "ik_cost", "ik_stop", "ik_iters", "ik_status", "X", "F"):
+        assert np.array_equal(on[k], off[k]), k
+    n = on["ik_iters"]
+    for i in np.where(took)[0][:6]:                  # ... the per-iteration trace too: same accepted step lengths, same regularisation
+        assert np.array_equal(on["ik_trace"][i, :n[i]], off["ik_trace"][i, :n[i]]), i
+    assert np.all(on["ik_fused_iters"][took] <= n[took]) and np.all(on["ik_fused_iters"][took] >= n[took] - 6)

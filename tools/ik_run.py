@@ -17,6 +17,10 @@ if len(sys.argv) > 4:
     lib.bmpc_ik_set_all_steps(int(sys.argv[4]))
 if len(sys.argv) > 5:
     lib.bmpc_ik_set_gains_wave_below(int(sys.argv[5]))
+if os.environ.get("IK_EXPRESS"):
+    lib.bmpc_ik_set_express_capacity(int(os.environ["IK_EXPRESS"]))
+if os.environ.get("IK_EXPRESS_NEAR"):
+    lib.bmpc_ik_set_express_near(float(os.environ["IK_EXPRESS_NEAR"]))
 if os.environ.get("IK_BLOCKING_WAITS"):
     lib.bmpc_ik_set_blocking_waits(int(os.environ["IK_BLOCKING_WAITS"]))
 robot = "go2" if cfg == "go2_h60" else "solo12"
@@ -50,3 +54,10 @@ h = hashlib.sha256()
 for k in ("xs", "us", "ik_iters", "ik_cost"):
     h.update(np.ascontiguousarray(r[k]).tobytes())
 print("results digest", h.hexdigest()[:16], "ddp loop iterations", r["ddp_loop_iters"])
+# the fused kernel's telemetry of the longest-running problem (cycles in derivative + Riccati pass / line search, ticks, iterations)
+i = int(np.argmax(r["ik_iters"]))
+oq = kb.off["k"] + wb.ik_T * 18
+t = kb.ws[i, oq:oq + 8].cpu().numpy()
+if t[3] > 0 and t[3] < 200:
+    print("fused kernel, problem %d (%d iterations): %d turns, cycles per turn: phase A %.0f (%.1f ticks), phase B %.0f" % (i, r["ik_iters"][i], t[3], t[0] / t[3], t[2] / t[3], t[1] / t[3]))
+    print("   recursion wave per turn: start -> first node %.0f, nodes %.0f, after the last node %.0f; line search inside its role %.0f" % tuple(t[4:8] / t[3]))
