@@ -139,6 +139,15 @@ __device__ __forceinline__ long slot_problem(const IkBatchArgs &a, long slot) {
     return p;
 }
 
+// A workgroup of ONE wave (the backward pass; the one-wave derivative pass): its LDS accesses execute in program order, so what a barrier has to provide
+// is only that the compiler keeps them in that order and that earlier LDS operations have completed.  __syncthreads() would
+// also wait for every outstanding GLOBAL load (s_waitcnt vmcnt(0)) -- here that is the prefetched L_xx row of the node, which
+// is not needed before the elimination and should keep flying across the exchanges in between.
+__device__ __forceinline__ void wave_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ------------------------------------------------------------------------------- init ---
 __global__ void ik_init_kernel(const IkBatchArgs a) {
     const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -496,6 +505,57 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a
 #endif
 }
 
+// The same derivative pass by ONE wave per node pair, the pieces one after the other (as the fused kernel's producer waves run
+// them): for launches with more workgroups than the chip has wave slots.  There the two-wave kernel is bound by the slots it
+// holds, and its second wave holds one through the walk only to wait at the barrier; a single wave spends 37 % fewer
+// wave-cycles per pair (the pair's latency, which is what counts when few problems are left, is 25 % longer).
+// Two such waves share a workgroup (and its copy of the robot model), each with a node pair of its own: 36.7 KB of LDS per
+// workgroup, four workgroups = eight waves per CU, which is what the registers allow.
+struct alignas(16) Calc1Lds { CalcNode nd[2][kCalcNodes]; RobotModelDev m; };
+__global__ __launch_bounds__(128, 2) void ik_calcdiff1_kernel(const IkBatchArgs a) {
+    __shared__ Calc1Lds s;
+    const int nn = a.T + 1, groups = (nn + kCalcNodes - 1) / kCalcNodes;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        const int *src = reinterpret_cast<const int *>(a.model);
+        int *dst = reinterpret_cast<int *>(&s.m);
+        for (int i = threadIdx.x; i < (int)(sizeof(RobotModelDev) / sizeof(int)); i += 128) dst[i] = src[i];
+    }
+    __syncthreads();        // (the only workgroup barrier: from here on the two waves have nothing to do with each other)
+    const long unit = (long)blockIdx.x * 2 + wave;
+    const long b = slot_problem(a, unit / groups);
+    if (b < 0) return;
+    const int t0 = (int)(unit % groups) * kCalcNodes;
+    const IkLayout L = IkLayout::make(a.T);
+    double *ws = a.ws + b * L.total;
+    if (ws[L.scal + S_DONE] != 0.0 || ws[L.scal + S_RECALC] == 0.0) return;
+    const RobotModelDev &m = s.m;
+    CalcNode (&nd)[kCalcNodes] = s.nd[wave];
+    const double *state_w0 = batch_ptr(a.state_w, a.s_state_w, b), *ctrl_w0 = batch_ptr(a.ctrl_w, a.s_ctrl_w, b);
+    UNROLL_RBD for (int h = 0; h < kCalcNodes; ++h) {
+        const int t = t0 + h;
+        if (t < nn) {
+            CalcNode &q = nd[h];
+            if (lane < kNX) q.x[lane] = ws[L.xs + (long)t * kNX + lane];
+            if (lane < kNV) q.u[lane] = t == a.T ? 0.0 : ws[L.us + (long)t * kNV + lane];
+        }
+    }
+    wave_sync();
+    const int hs = lane >> 5, hl = lane & 31, tw = t0 + hs;
+    const bool wvalid = tw < nn;
+    CalcNode &qw = nd[hs];
+    NodeTasks tkw{a.tasks + (b * nn + (wvalid ? tw : t0)) * kNodeTaskDoubles};
+    PartWalk pw;
+    double Rb[9], pb[3], Vb[6];
+    if (wvalid && hl < kNV) calc_walk(m, qw, tkw, hl, Rb, pb, Vb, pw);
+    if (wvalid) calc_fetch_state(qw, ws, L, tw, hl);
+    wave_sync();
+    if (wvalid && hl < kNV) calc_columns(m, qw, tkw, hl, pw);
+    wave_sync();
+    calc_assemble(a, b, t0, nd[0], ws, L, lane, state_w0, ctrl_w0, ws + L.fs + (long)t0 * kNDX);
+    if (t0 + 1 < nn) calc_assemble(a, b, t0 + 1, nd[1], ws, L, lane, state_w0, ctrl_w0, ws + L.fs + (long)(t0 + 1) * kNDX);
+}
+
 // --------------------------------------------------------------------------- backward ---
 // One wave per problem, no cross-wave barrier.  Lane r < 36 owns ROW r of every 36x36 matrix of the
 // Riccati step in registers; LDS (14.6 KB per wave) is only the exchange medium: one transposition per
@@ -602,15 +662,6 @@ __device__ __forceinline__ void apply_FxT(double (&x)[kNDX], unsigned a6_addr, u
         x[kNV + k] = dt * v + x[kNV + k];
     }
     UNROLL_RBD for (int k = 6; k < kNV; ++k) x[kNV + k] = dt * x[k] + x[kNV + k];
-}
-
-// The workgroup of the backward pass is ONE wave: its LDS accesses execute in program order, so what a barrier has to provide
-// is only that the compiler keeps them in that order and that earlier LDS operations have completed.  __syncthreads() would
-// also wait for every outstanding GLOBAL load (s_waitcnt vmcnt(0)) -- here that is the prefetched L_xx row of the node, which
-// is not needed before the elimination and should keep flying across the exchanges in between.
-__device__ __forceinline__ void wave_sync() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
 }
 
 // NWB = 2 (few problems still iterating): the gains K = L^-T Y, k = L^-T y_u -- the back substitutions, their
@@ -1848,9 +1899,11 @@ hipError_t ik_launch_state(const IkBatchArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(ik_state_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, a);
     return hipGetLastError();
 }
+int g_calcdiff_one_wave_above = 1024;     // node pairs per launch above which one wave takes a pair (the two-wave kernel has 1024 pairs resident on an MI355X)
 hipError_t ik_launch_calcdiff(const IkBatchArgs &a, hipStream_t st) {
     const long n = launch_problems(a) * ((a.T + 1 + 1) / 2);   // two nodes per workgroup
-    hipLaunchKernelGGL(ik_calcdiff_kernel, dim3((unsigned)n), dim3(128), 0, st, a);
+    if (n > g_calcdiff_one_wave_above) hipLaunchKernelGGL(ik_calcdiff1_kernel, dim3((unsigned)((n + 1) / 2)), dim3(128), 0, st, a);
+    else hipLaunchKernelGGL(ik_calcdiff_kernel, dim3((unsigned)n), dim3(128), 0, st, a);
     return hipGetLastError();
 }
 hipError_t ik_launch_backward(const IkBatchArgs &a, hipStream_t st) {
