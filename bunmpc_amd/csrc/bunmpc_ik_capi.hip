@@ -197,7 +197,13 @@ struct ActiveWord {
             HIP_TRY(hipEventCreateWithFlags(&evs[0][k], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&evs[1][k], hipEventDisableTiming | hipEventBlockingSync));
         }
-        HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        // A stream of the HIGHEST priority: the HIP runtime multiplexes streams of one priority onto a few hardware queues, and
+        // sharing one with the caller's stream would put the lane's persistent kernel (milliseconds) IN FRONT of the batch's own
+        // kernels instead of beside them (seen in bench.py, whose process holds a dozen streams: 19.8 ms per batch solve instead
+        // of 15.1); queues are per priority level, and the lane's workgroups should be placed first anyway.
+        int pr_least = 0, pr_greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, pr_greatest));
         HIP_TRY(hipEventCreateWithFlags(&x_go, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&x_done, hipEventDisableTiming | hipEventBlockingSync));
         return BMPC_OK;
