@@ -166,7 +166,7 @@ __global__ void ik_init_kernel(const IkBatchArgs a) {
     s[S_COST] = 0; s[S_XREG] = 1e-9; s[S_D1] = 0; s[S_D2] = 0; s[S_STOP] = 0; s[S_FEAS] = 0; s[S_WASFEAS] = 0;
     s[S_DONE] = 0; s[S_ITERS] = 0; s[S_RECALC] = 1; s[S_STATUS] = 0; s[S_WIDE] = 0; s[S_WIDENOW] = 0;
     ws[L.arrive] = 0.0;          // (read as an unsigned counter)
-    for (int k = 0; k < 8; ++k) ws[L.Qu + k] = 0.0;      // the fused kernel's telemetry (the Qu slot is unused by the solver)
+    for (int k = 0; k < 12; ++k) ws[L.Qu + k] = 0.0;     // the fused kernel's telemetry (the Qu slot is unused by the solver)
     if (a.list) a.list[b] = (int)b;
     if (b == 0) { *a.active = a.B; if (a.count) { a.count[0] = a.B; a.count[1] = 0; a.wcount[0] = 0; a.wcount[1] = 0; a.err[0] = 0; a.err[1] = 0; a.near[0] = 0; a.near[1] = 0;
                                                for (int k = 0; k < 4; ++k) a.xmeta[k] = 0; } }
@@ -686,21 +686,27 @@ struct FusedCtl {
     double node_cost[64];   // the node costs (the multi-kernel path parks them in the nodes' gap slots)
     long long t_phase;      // telemetry: cycle count at the start of the phase, and the recursion wave's split of it
     long long tele[4];      // [start -> first node, first node -> last node done, last node done -> the role returns, line search inside the role]
+    long long wait[4];      // cycles each wave spent at the tick barriers
 };
 // tick watchdog: more ticks than any phase can need means a broken protocol; every wave counts the same barriers, so all of
 // them see the limit at the same tick and unwind together (no wave is left behind at a barrier)
 struct Ticker {
     int n = 0, limit = 0;
     bool dead = false;
+    long long wait = 0;     // telemetry: cycles spent at the tick barriers
 };
 // the recursion's and the gains wave's barrier: LDS traffic complete (their hand-over goes through LDS)
 __device__ __forceinline__ void tick_lds(Ticker &tk) {
+    const long long t0 = __builtin_readcyclecounter();
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    tk.wait += (long long)__builtin_readcyclecounter() - t0;
     if (++tk.n > tk.limit) tk.dead = true;
 }
 // the producers' barrier: their global stores (the node derivatives) complete as well
 __device__ __forceinline__ void tick_mem(Ticker &tk) {
+    const long long t0 = __builtin_readcyclecounter();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    tk.wait += (long long)__builtin_readcyclecounter() - t0;
     if (++tk.n > tk.limit) tk.dead = true;
 }
 __device__ __forceinline__ int lds_flag(const int &f) { return *const_cast<const volatile int *>(&f); }
@@ -1655,6 +1661,7 @@ __device__ __noinline__ int fused_role_recursion(long b_, int limit) {
     const IkBatchArgs a = fused_args();
     Ticker tk; tk.limit = uni(limit);
     backward_main_wave<2, true>(a, uni(b_), g_fused.bw, (int)(threadIdx.x & 63), &g_fused.ctl, tk);
+    if ((threadIdx.x & 63) == 0) g_fused.ctl.wait[0] += tk.wait;
     return tk.dead ? -1 : tk.n;
 }
 __device__ __noinline__ int fused_role_gains(long b_, int limit) {
@@ -1663,12 +1670,14 @@ __device__ __noinline__ int fused_role_gains(long b_, int limit) {
     double *ws = a.ws + uni(b_) * L.total;
     Ticker tk; tk.limit = uni(limit);
     backward_gains_wave<true>(g_fused.bw, ws, ws + L.scal, L, a.T, (int)(threadIdx.x & 63), &g_fused.ctl, tk);
+    if ((threadIdx.x & 63) == 0) g_fused.ctl.wait[1] += tk.wait;
     return tk.dead ? -1 : tk.n;
 }
 __device__ __noinline__ int fused_role_producer(long b_, int limit) {
     const IkBatchArgs a = fused_args();
     Ticker tk; tk.limit = uni(limit);
     producer_wave(a, uni(b_), g_fused, uni((int)(threadIdx.x >> 6)) - 2, (int)(threadIdx.x & 63), tk);
+    if ((threadIdx.x & 63) == 0) g_fused.ctl.wait[threadIdx.x >> 6] += tk.wait;
     return tk.dead ? -1 : tk.n;
 }
 __device__ __noinline__ void fused_role_line_search(long b_) {
@@ -1700,7 +1709,7 @@ __global__ __launch_bounds__(256) void ik_fused_kernel(const IkBatchArgs a, cons
     }
     if (threadIdx.x < 64) s.ctl.ready[threadIdx.x] = 0;
     if (threadIdx.x == 0) { s.ctl.state_ready = 0; s.ctl.hand_count = 0; s.ctl.done_flag = 0; s.ctl.stamp = 0; s.ctl.abort_code = 0; s.args = a;
-                            for (int k = 0; k < 4; ++k) s.ctl.tele[k] = 0; }
+                            for (int k = 0; k < 4; ++k) { s.ctl.tele[k] = 0; s.ctl.wait[k] = 0; } }
     __syncthreads();
     const int limit = 24 * (a.T + 8);      // a pass takes T + ~6 ticks; the regularisation can restart it 18 times (1e-9 ... 1e9)
     long long cyc_a = 0, cyc_b = 0, ticks = 0, turns = 0;       // telemetry (tools/ik_run.py): cycles in the two phases, ticks, iterations
@@ -1724,7 +1733,7 @@ __global__ __launch_bounds__(256) void ik_fused_kernel(const IkBatchArgs a, cons
     }
     if (threadIdx.x == 0) {     // (the Qu slot of the workspace is unused by the solver)
         ws[L.Qu + 0] = (double)cyc_a; ws[L.Qu + 1] = (double)cyc_b; ws[L.Qu + 2] = (double)ticks; ws[L.Qu + 3] = (double)turns;
-        for (int k = 0; k < 4; ++k) ws[L.Qu + 4 + k] = (double)s.ctl.tele[k];
+        for (int k = 0; k < 4; ++k) { ws[L.Qu + 4 + k] = (double)s.ctl.tele[k]; ws[L.Qu + 8 + k] = (double)s.ctl.wait[k]; }
     }
 }
 
