@@ -674,13 +674,17 @@ __device__ __forceinline__ void bwd_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // whole DDP iterations without leaving the chip.  Its derivative pass and Riccati pass share ONE sequence of workgroup barriers
 // ("ticks"): wave 0 runs the recursion (a node per tick), wave 1 the gains one node behind, waves 2 and 3 produce the node
 // derivatives ahead of the recursion.  Every wave executes exactly one barrier per tick whatever it has to do in it (a node, a
-// producer step, or nothing), and all of them leave the phase after the same barrier (done_flag, read right after a barrier).
+// producer step, or nothing), and all of them leave the phase after the same barrier: the gains wave announces the NUMBER of the
+// last tick (done_tick) and a wave leaves once its own count has reached it.  (A plain "done" flag is not enough: set between
+// barriers n and n + 1, it can be seen by a wave that reads it late after barrier n and by another only after n + 1 -- they
+// would leave one barrier apart and every later barrier of the kernel would pair up wrongly.  That version ran clean for a day
+// and then, with a changed code layout, handed stale node costs to the line search of one problem in twenty.)
 // Flags compare against `stamp` (bumped once per phase), so nothing has to be cleared.
 struct FusedCtl {
     int ready[64];          // node t's derivatives are in the workspace (stamp)
     int state_ready;        // ... the scalar chains of every node (state residual, Euler step: state_node) (stamp)
     int hand_count;         // nodes (and end markers) the recursion has handed to the gains wave in this phase
-    int done_flag;          // the phase is over (stamp): set by the gains wave between two barriers
+    int done_tick;          // the phase ends with the tick of this number (INT_MAX while it is open): set by the gains wave
     int stamp;
     int abort_code;         // != 0: the tick watchdog fired (a protocol bug, never a data condition): the kernel reports and leaves
     double node_cost[64];   // the node costs (the multi-kernel path parks them in the nodes' gap slots)
@@ -721,12 +725,12 @@ __device__ __forceinline__ void backward_gains_wave(BackwardLds<2> &s, double *w
         int t;
         if (FUSED) {
             tick_lds(tk);
-            if (tk.dead || lds_flag(ctl->done_flag) == ctl->stamp) return;     // (every wave leaves after this same barrier)
+            if (tk.dead || tk.n >= lds_flag(ctl->done_tick)) return;     // (every wave leaves after this same barrier)
             if (lds_flag(ctl->hand_count) <= k) continue;                       // a tick without a hand-over (the recursion waits for a node)
             t = s.tnode[k & 1];
             if (t < 0) {    // the pass is over (-1) or was given up (-2): nothing else is handed over in this phase
                 if (t == -1 && lane == kQuLane) { sc[S_D1] = d1; sc[S_STOP] = st; }
-                if (lane == 0) ctl->done_flag = ctl->stamp;
+                if (lane == 0) ctl->done_tick = tk.n + 1;
                 ++k;
                 continue;
             }
@@ -770,7 +774,7 @@ __device__ __forceinline__ void backward_gains_wave(BackwardLds<2> &s, double *w
 
 // The recursion's wave.  FUSED: inside ik_fused_kernel -- barriers are ticks, a node waits (whole ticks) until the producer waves
 // have left its derivatives in the workspace, the total cost is summed at the end of the pass (the node costs come from LDS) and
-// the wave never returns early: it leaves with every other wave of the workgroup, after the barrier that follows done_flag.
+// the wave never returns early: it leaves with every other wave of the workgroup, after the tick the gains wave names (done_tick).
 template <int NWB, bool FUSED>
 __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b, BackwardLds<NWB> &s, int lane, FusedCtl *ctl, Ticker &tk) {
     const IkLayout L = IkLayout::make(a.T);
@@ -1107,7 +1111,7 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
         if (recalc && !gave_up && lane == 0) { double c = 0.0; for (int t = 0; t <= T; ++t) c += ctl->node_cost[t]; sc[S_COST] = c; }
         for (;;) {
             tick_lds(tk);
-            if (tk.dead || lds_flag(ctl->done_flag) == ctl->stamp) break;
+            if (tk.dead || tk.n >= lds_flag(ctl->done_tick)) break;
         }
         if (lane == 0) {
             ctl->tele[0] += t_first - ctl->t_phase; ctl->tele[1] += t_last - t_first; ctl->tele[2] += (long long)__builtin_readcyclecounter() - t_last;
@@ -1193,10 +1197,18 @@ __device__ __forceinline__ void fwd_sync() {
 // FUSED (ik_fused_kernel: NW = 4, wave 3 takes no part but keeps the barriers): the problem is given, its four step lengths run
 // side by side (further rounds of four in the same call), nothing is appended to the active list, and no wave returns before
 // the last barrier.
-template <int NW, bool FUSED>
+// ROLES (bit 0: the chain, bit 1: the robot walks and the residual costs, bit 2: the state-regularisation residual): what THIS wave
+// does, a compile-time constant.  The workgroup's waves run different instantiations of this one body, each as a non-inlined
+// function with a register allocation of its own (forward_role below): as run-time conditions inside one function the roles'
+// register arrays interfered in hipcc's allocator -- 512 registers and 124 spilled ones for code that needs half of that per role.
+constexpr int kRoleChain = 1, kRoleCost = 2, kRoleReg = 4;
+constexpr int forward_roles(int NW, int wave) {
+    return NW == 1 ? 7 : wave == 0 ? (NW == 2 ? kRoleChain | kRoleReg : kRoleChain) : wave == 1 ? kRoleCost : (wave == 2 && NW >= 3) ? kRoleReg : 0;
+}
+template <int NW, bool FUSED, int ROLES>
 __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s, long b_fused) {
     const int lane = threadIdx.x & 63, wave = NW > 1 ? (int)(threadIdx.x >> 6) : 0, si = lane / kFwdLanes, l = lane % kFwdLanes;
-    const bool do_chain = NW == 1 || wave == 0, do_cost = NW == 1 || wave == 1, do_reg = NW == 1 || wave == (NW == 2 ? 0 : 2);
+    constexpr bool do_chain = (ROLES & kRoleChain) != 0, do_cost = (ROLES & kRoleCost) != 0, do_reg = (ROLES & kRoleReg) != 0;
     const bool spec = FUSED || a.fwd_spec != 0;
     // fwd_spec == 4: THREE workgroups per problem, workgroup g trying step lengths 2^-(4g + s): all ten in one round, on
     // separate CUs (inside one workgroup the register budget of seven waves did not allow it); the last of the
@@ -1482,7 +1494,7 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
             }
             break;
         } else {
-            if (l == 0) { s.vote[si] = pass ? 1.0 : 0.0; s.ctry[si] = ctry; }
+            if (do_chain && l == 0) { s.vote[si] = pass ? 1.0 : 0.0; s.ctry[si] = ctry; }      // (every wave holds the same numbers; one writes)
             fwd_sync<NW>();
             int w = -1;
             UNROLL_RBD for (int k = kFwdSub - 1; k >= 0; --k) if (s.vote[k] != 0.0) w = k;    // first in SolverDDP's order
@@ -1546,10 +1558,27 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
     }
 }
 
+// LDS of the line-search kernels, at file scope so that the role functions can name it (as g_fused, further down)
+struct alignas(16) ForwardShared { ForwardLds s; IkBatchArgs args; };
+__shared__ ForwardShared g_fwd;
+__device__ __forceinline__ IkBatchArgs uniform_args(const IkBatchArgs &g);      // every field through v_readfirstlane (defined with the fused kernel)
+template <int NW, int ROLES>
+__device__ __noinline__ void forward_role() {
+    const IkBatchArgs a = uniform_args(g_fwd.args);
+    forward_body<NW, false, ROLES>(a, g_fwd.s, -1);
+}
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a) {
-    __shared__ ForwardLds s;
-    forward_body<NW, false>(a, s, -1);
+    if (NW == 1) {      // one wave does everything: nothing to separate
+        forward_body<1, false, 7>(a, g_fwd.s, -1);
+        return;
+    }
+    if (threadIdx.x == 0) g_fwd.args = a;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6;
+    if (wave == 0) forward_role<NW, forward_roles(NW, 0)>();
+    else if (wave == 1) forward_role<NW, forward_roles(NW, 1)>();
+    else forward_role<NW, forward_roles(NW, 2)>();
 }
 
 // ------------------------------------------------------------------------------ fused ---
@@ -1581,8 +1610,7 @@ __device__ __forceinline__ long uni(long v) {
                   (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)v));
 }
 template <class P> __device__ __forceinline__ P *uni(P *p) { return reinterpret_cast<P *>(uni((long)p)); }
-__device__ __forceinline__ IkBatchArgs fused_args() {
-    const IkBatchArgs &g = g_fused.args;
+__device__ __forceinline__ IkBatchArgs uniform_args(const IkBatchArgs &g) {
     IkBatchArgs a;
     a.B = uni(g.B); a.T = uni(g.T); a.maxiter = uni(g.maxiter); a.fwd_spec = uni(g.fwd_spec); a.bwd_waves = uni(g.bwd_waves);
     a.list = uni(g.list); a.count = uni(g.count); a.wide = uni(g.wide); a.wcount = uni(g.wcount); a.err = uni(g.err); a.near = uni(g.near);
@@ -1592,6 +1620,7 @@ __device__ __forceinline__ IkBatchArgs fused_args() {
     a.sn_state_w = uni(g.sn_state_w); a.sn_x_reg = uni(g.sn_x_reg); a.sn_ctrl_w = uni(g.sn_ctrl_w); a.ws = uni(g.ws); a.active = uni(g.active); a.near_stop = g.near_stop;
     return a;
 }
+__device__ __forceinline__ IkBatchArgs fused_args() { return uniform_args(g_fused.args); }
 
 // Producer wave p (0 / 1) of the fused kernel: node pairs p, p + 2, ... counted from the terminal node down (pair j = nodes
 // T - 2j, T - 2j - 1), two ticks per pair -- [stage, walk, columns] [state terms in, assemble A, assemble B] -- so the two of them
@@ -1612,12 +1641,16 @@ __device__ __forceinline__ void producer_wave(const IkBatchArgs &a, long b, Fuse
     CalcNode &qw = s.nd[p][hs];
     int pair = p, phase = p == 1 ? 0 : 1;
     bool first = true;
+    // A flag is raised only once the global stores it stands for have completed: the recursion reads flags in the middle of ticks
+    // too (whether node t - 1 can be requested a node ahead), not only right behind the barrier that follows the producer's step.
+    auto stores_done = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
     for (;;) {
         if (!recalc) {
             // the line search of the iteration before accepted nothing: the derivatives in the workspace are still those of this trajectory
             if (first && p == 0) { if (lane <= T) ctl.ready[lane] = stamp; if (lane == 0) ctl.state_ready = stamp; }
         } else if (phase == 0) {
             if (lane <= T) state_node(a, b, lane, ws, L);
+            stores_done();
             if (lane == 0) ctl.state_ready = stamp;
             phase = 1;
         } else if (pair < npairs) {
@@ -1646,13 +1679,14 @@ __device__ __forceinline__ void producer_wave(const IkBatchArgs &a, long b, Fuse
                 wave_sync();
                 calc_assemble(a, b, tA, s.nd[p][0], ws, L, lane, state_w0, ctrl_w0, &ctl.node_cost[tA]);
                 if (tB >= 0) calc_assemble(a, b, tB, s.nd[p][1], ws, L, lane, state_w0, ctrl_w0, &ctl.node_cost[tB]);
+                stores_done();
                 if (lane == 0) { ctl.ready[tA] = stamp; if (tB >= 0) ctl.ready[tB] = stamp; }
                 phase = 1; pair += 2;
             }
         }
         first = false;
         tick_mem(tk);
-        if (tk.dead || lds_flag(ctl.done_flag) == stamp) return;
+        if (tk.dead || tk.n >= lds_flag(ctl.done_tick)) return;
     }
 }
 
@@ -1680,10 +1714,11 @@ __device__ __noinline__ int fused_role_producer(long b_, int limit) {
     if ((threadIdx.x & 63) == 0) g_fused.ctl.wait[threadIdx.x >> 6] += tk.wait;
     return tk.dead ? -1 : tk.n;
 }
+template <int ROLES>
 __device__ __noinline__ void fused_role_line_search(long b_) {
     const long long t0 = __builtin_readcyclecounter();
     const IkBatchArgs a = fused_args();
-    forward_body<4, true>(a, g_fused.fw, uni(b_));
+    forward_body<4, true, ROLES>(a, g_fused.fw, uni(b_));
     if (threadIdx.x == 0) g_fused.ctl.tele[3] += (long long)__builtin_readcyclecounter() - t0;
 }
 
@@ -1708,7 +1743,7 @@ __global__ __launch_bounds__(256) void ik_fused_kernel(const IkBatchArgs a, cons
         for (int i = threadIdx.x; i < (int)(sizeof(RobotModelDev) / sizeof(int)); i += 256) dst[i] = src[i];
     }
     if (threadIdx.x < 64) s.ctl.ready[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { s.ctl.state_ready = 0; s.ctl.hand_count = 0; s.ctl.done_flag = 0; s.ctl.stamp = 0; s.ctl.abort_code = 0; s.args = a;
+    if (threadIdx.x == 0) { s.ctl.state_ready = 0; s.ctl.hand_count = 0; s.ctl.done_tick = 0x7fffffff; s.ctl.stamp = 0; s.ctl.abort_code = 0; s.args = a;
                             for (int k = 0; k < 4; ++k) { s.ctl.tele[k] = 0; s.ctl.wait[k] = 0; } }
     __syncthreads();
     const int limit = 24 * (a.T + 8);      // a pass takes T + ~6 ticks; the regularisation can restart it 18 times (1e-9 ... 1e9)
@@ -1716,7 +1751,7 @@ __global__ __launch_bounds__(256) void ik_fused_kernel(const IkBatchArgs a, cons
     for (int turn = 0; turn <= a.maxiter; ++turn) {      // one DDP iteration per turn (the forward pass ends the problem at maxiter)
         if (sc[S_DONE] != 0.0) break;
         const long long c0 = __builtin_readcyclecounter();
-        if (threadIdx.x == 0) { s.ctl.stamp += 1; s.ctl.hand_count = 0; s.ctl.t_phase = c0; }
+        if (threadIdx.x == 0) { s.ctl.stamp += 1; s.ctl.hand_count = 0; s.ctl.done_tick = 0x7fffffff; s.ctl.t_phase = c0; }
         __syncthreads();
         const int nt = wave == 0 ? fused_role_recursion(b, limit) : wave == 1 ? fused_role_gains(b, limit) : fused_role_producer(b, limit);
         if (nt < 0) {      // every wave has counted the same barriers: all of them are here, none waits at one
@@ -1727,7 +1762,10 @@ __global__ __launch_bounds__(256) void ik_fused_kernel(const IkBatchArgs a, cons
         const long long c1 = __builtin_readcyclecounter();
         cyc_a += c1 - c0; ticks += nt; ++turns;
         if (sc[S_DONE] != 0.0) break;       // the pass was given up at the regularisation's ceiling
-        fused_role_line_search(b);
+        if (wave == 0) fused_role_line_search<forward_roles(4, 0)>(b);
+        else if (wave == 1) fused_role_line_search<forward_roles(4, 1)>(b);
+        else if (wave == 2) fused_role_line_search<forward_roles(4, 2)>(b);
+        else fused_role_line_search<forward_roles(4, 3)>(b);
         __syncthreads();
         cyc_b += __builtin_readcyclecounter() - c1;
     }

@@ -62,3 +62,5 @@ if t[3] > 0 and t[3] < 200:
     print("fused kernel, problem %d (%d iterations): %d turns, cycles per turn: phase A %.0f (%.1f ticks), phase B %.0f" % (i, r["ik_iters"][i], t[3], t[0] / t[3], t[2] / t[3], t[1] / t[3]))
     print("   recursion wave per turn: start -> first node %.0f, nodes %.0f, after the last node %.0f; line search inside its role %.0f" % tuple(t[4:8] / t[3]))
     print("   cycles per turn at the tick barriers: recursion %.0f, gains %.0f, producers %.0f / %.0f" % tuple(t[8:12] / t[3]))
+al = kb.active_list.cpu().numpy()
+print("express lane: xmeta (taken, count, iteration, -)", al[-260:-256].tolist(), "near counts", al[-262:-260].tolist())
