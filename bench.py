@@ -322,7 +322,7 @@ def kinodyn_leg(D, B, admm_iters, maxit, config="solo12_h20", steps=3, warmup=1,
                      "tests/test_parity_envelope_gpu.py",
            # HBM view of the whole solve (every kernel of one KinoDynMP.optimize batch): SURVEY 8d's per-solve bytes x B over the
            # wall time of a solve; `dominant_kernel` the same bytes' IK share over that kernel's summed launches.  The path is
-           # latency / issue bound, so the fraction is tiny by construction.
+           # latency / issue bound (EXPERIMENTS.md 9), so the fraction is tiny by construction.
            "roofline": {"bound": "hbm", "achieved": abytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": abytes / dt / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(wkey),
                         "scope": "all kernels of one batch solve", "algorithmic_bytes_per_solve_batch": abytes,

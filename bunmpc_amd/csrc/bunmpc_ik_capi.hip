@@ -165,7 +165,7 @@ bunmpc::IkBatchArgs make_args(int B, int T, int maxiter, const bmpc_model *model
 std::atomic<int> g_spec_line_search_below{1024};
 std::atomic<int> g_all_steps{0};  // at most this many active problems: all ten step lengths at once, three workgroups per problem
                                   // (0 = never, the default: measured on the MI355X it gains < 1 % on the Go2 H = 60 batch at <= 85 -- one workgroup of
-                                  // three waves per CU is the forward kernel's residency -- and loses 2 % on Solo12)
+                                  // three waves per CU is the forward kernel's residency -- and loses 2 % on Solo12, EXPERIMENTS.md 9)
 std::atomic<int> g_gains_wave_below{512};   // at most this many active problems: the backward pass gives each a second wave for the gains
                                   // (two waves per problem on the MI355X's 1024 SIMDs; no effect on results)
 std::atomic<int> g_blocking_waits{1};       // the DDP loop's host waits sleep on an interrupt (hipEventBlockingSync) instead of spinning

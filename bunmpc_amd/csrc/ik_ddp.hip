@@ -664,7 +664,7 @@ __device__ __forceinline__ void apply_FxT(double (&x)[kNDX], unsigned a6_addr, u
     UNROLL_RBD for (int k = 6; k < kNV; ++k) x[kNV + k] = dt * x[k] + x[kNV + k];
 }
 
-// NWB = 2 (few problems still iterating): the gains K = L^-T Y, k = L^-T y_u -- the back substitutions, their
+// NWB = 2 (few problems still iterating, EXPERIMENTS.md 9): the gains K = L^-T Y, k = L^-T y_u -- the back substitutions, their
 // stores and the terms of the expected improvement that need k -- are for the forward pass, not for the next node of the
 // recursion (V_xx = Q_xx - Y^T Y and V_x = Q_x - Y^T y_u come from the forward substitutions alone).  A second wave takes
 // them over, one node behind: the recursion hands it the factor and Y through LDS and goes on.
@@ -1211,7 +1211,7 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
     constexpr bool do_chain = (ROLES & kRoleChain) != 0, do_cost = (ROLES & kRoleCost) != 0, do_reg = (ROLES & kRoleReg) != 0;
     const bool spec = FUSED || a.fwd_spec != 0;
     // fwd_spec == 4: THREE workgroups per problem, workgroup g trying step lengths 2^-(4g + s): all ten in one round, on
-    // separate CUs (inside one workgroup the register budget of seven waves did not allow it); the last of the
+    // separate CUs (inside one workgroup the register budget of seven waves did not allow it, EXPERIMENTS.md 9); the last of the
     // three to finish takes SolverDDP's decision for the problem
     const bool all10_batch = !FUSED && NW == 3 && a.fwd_spec == 4;
     // ... or for the flagged problems only (S_WIDENOW, set by the pass before): their two extra workgroups are the FIRST

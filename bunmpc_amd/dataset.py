@@ -7,7 +7,7 @@ h5py is not part of this image, so `save()` writes the same four arrays to `data
 its hydra config next to the data, once (`config.pkl` = `pickle.dump(OmegaConf.to_container(cfg, resolve=True))`,
 `data_collection.py:116-122`: a plain dict of builtins): written here the same way with the standard library's pickle, plus a
 human-readable `config.json` beside it.  A hand-rolled HDF5 container stays unbuilt: nothing in this image can read one back,
-so it could not be checked.
+so it could not be checked (EXPERIMENTS.md 10).
 """
 import json
 import os

@@ -249,7 +249,7 @@ void bmpc_ik_layout(int n_col, long *offsets8);      /* xs, us, scalars, K, k, f
 void bmpc_ik_layout_trace(int n_col, long *offset, int *iters, int *width);
 /* Line-search scheduling of the batched DDP (no effect on results): while at most n_active problems are still
  * iterating, four step lengths of a problem are tried side by side (one wave per problem) instead of one after the
- * other (four problems per wave); with at most bmpc_ik_set_all_steps' n_active left (default 0 = never: no measurable gain), all ten step
+ * other (four problems per wave); with at most bmpc_ik_set_all_steps' n_active left (default 0 = never: no measurable gain, EXPERIMENTS.md 9), all ten step
  * lengths at once on three workgroups per problem.  Default 1024 (one wave per SIMD of an MI355X); 0 = never.  Both return
  * the old value. */
 int bmpc_ik_set_speculative_below(int n_active);

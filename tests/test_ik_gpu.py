@@ -176,7 +176,7 @@ def test_kinodyn_batch_matches_per_problem_oracle(model, oracle):
 
 def test_kinodyn_batch_go2_h60(oracle):
     """BASELINE config 5 at test size: synthetic Go2 (tools/make_go2_model.py), trot, H=60, H_ik=30.
-    The centroidal part is compared in the long-horizon envelope (DESIGN.md 3: the two CPU
+    The centroidal part is compared in the long-horizon envelope (DESIGN.md 2: the two CPU
     restatements themselves differ by ~1e-4 there); the IK-DDP is compared exactly, on the
     references the GPU's own centroidal solution produced."""
     import dataclasses

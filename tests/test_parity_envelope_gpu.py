@@ -65,7 +65,7 @@ def test_ddp_problems_that_hit_maxiter_follow_the_cpu_twin():
     """Problems 2, 13 and 14 of the bench's Go2 H = 60 batch never reach SolverDDP's stopping threshold (|Q_u|^2 < 1e-9) within
     its 100 iterations.  Not a regularisation limit cycle: the regularisation stays at its floor (1e-9) and the cost falls
     monotonically -- the Gauss-Newton DDP converges linearly with partial steps (alpha 1/16 ... 1/2) on these plans and simply
-    runs out of iterations.  GPU and CPU twin must agree on every discrete decision along the way."""
+    runs out of iterations (EXPERIMENTS.md 9).  GPU and CPU twin must agree on every discrete decision along the way."""
     from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
     from oracle import ik_oracle_c as ic
     go2, wb = _go2_wb(16)

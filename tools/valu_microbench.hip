@@ -1,5 +1,5 @@
 // Microbenchmark: what one SIMD of gfx950 sustains for wave64 fp64 / fp32 / mov / DPP streams at
-// 1, 2 and 4 waves per SIMD.  Used to calibrate the fp64-VALU roofline quoted in DESIGN.md.
+// 1, 2 and 4 waves per SIMD.  Used to calibrate the fp64-VALU roofline quoted in DESIGN.md 4 and EXPERIMENTS.md 4.
 // Build: hipcc --offload-arch=gfx950 -O3 -o valu_microbench valu_microbench.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
