@@ -274,7 +274,7 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run, const
         for (int k = 0; k < chunk && it < a.maxiter; ++k, ++it) {
             a.iter = it;
             if (express_cap > 0 && !express_taken && it >= kExpressFirstIter && it <= kExpressLastIter) {
-                HIP_TRY(bunmpc::ik_launch_select(a, express_cap, st));
+                HIP_TRY(bunmpc::ik_launch_select(a, express_cap, sched.debug_inject == 2, st));
                 HIP_TRY(hipEventRecord(w.x_go, st));
                 HIP_TRY(hipStreamWaitEvent(w.side, w.x_go, 0));
                 HIP_TRY(bunmpc::ik_launch_fused_express(a, express_cap, w.side));

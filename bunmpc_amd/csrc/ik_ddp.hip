@@ -1785,7 +1785,7 @@ __global__ __launch_bounds__(256) void ik_fused_kernel(const IkBatchArgs a, cons
 // problems below the line creeps up over ten iterations, |Q_u|^2 does not rank its long runs -- and the lane stays shut.)  The
 // `cap` problems with the largest |Q_u|^2 move from the active list to xlist; the fused kernel enqueued behind this one on the
 // side stream takes them.  xmeta = {state (1: taken), count, iteration, -}.
-__global__ __launch_bounds__(1024) void ik_select_kernel(const IkBatchArgs a, int cap) {
+__global__ __launch_bounds__(1024) void ik_select_kernel(const IkBatchArgs a, int cap, int force) {
     __shared__ unsigned hist[16];
     __shared__ unsigned long long prefix_s;
     __shared__ int want_s, nx_s, nk_s, go_s;
@@ -1795,8 +1795,9 @@ __global__ __launch_bounds__(1024) void ik_select_kernel(const IkBatchArgs a, in
         const int n = a.count[cur];
         int c = cap < kExpressMax ? cap : kExpressMax;
         if (c > n / 8) c = n / 8;          // never more than an eighth of what is left
-        go_s = a.xmeta[0] == 0 && c > 0 && (unsigned)n <= (unsigned)a.B && (long)n * 50 >= (long)a.B * 49 && (long)a.near[cur] * 2 >= (long)a.B &&
-               (long)a.near[cur ^ 1] * 20 <= (long)a.B;     // (near[cur ^ 1]: the iteration before; this iteration's state kernel resets it)
+        go_s = a.xmeta[0] == 0 && c > 0 && (unsigned)n <= (unsigned)a.B &&
+               (force || ((long)n * 50 >= (long)a.B * 49 && (long)a.near[cur] * 2 >= (long)a.B &&
+                          (long)a.near[cur ^ 1] * 20 <= (long)a.B));     // (near[cur ^ 1]: the iteration before; this iteration's state kernel resets it)
         want_s = c; prefix_s = 0ull; nx_s = 0; nk_s = 0;
     }
     __syncthreads();
@@ -1967,8 +1968,8 @@ hipError_t ik_launch_forward(const IkBatchArgs &a, hipStream_t st) {
     return hipGetLastError();
 }
 // the express lane (a.iter = the iteration about to start): selection on `st`, the fused kernel for what it took on `side`
-hipError_t ik_launch_select(const IkBatchArgs &a, int cap, hipStream_t st) {
-    hipLaunchKernelGGL(ik_select_kernel, dim3(1), dim3(1024), 0, st, a, cap);
+hipError_t ik_launch_select(const IkBatchArgs &a, int cap, int force, hipStream_t st) {
+    hipLaunchKernelGGL(ik_select_kernel, dim3(1), dim3(1024), 0, st, a, cap, force);
     return hipGetLastError();
 }
 hipError_t ik_launch_fused_express(const IkBatchArgs &a, int cap, hipStream_t side) {

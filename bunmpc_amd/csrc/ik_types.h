@@ -128,7 +128,7 @@ hipError_t ik_launch_forward(const IkBatchArgs &a, hipStream_t s);
 // host_word_dev[0..3] = *active, index-check code, length of the list iteration next_iter runs over, express lane taken
 // (device alias of four host-mapped ints)
 hipError_t ik_launch_publish_active(const IkBatchArgs &a, int next_iter, int *host_word_dev, hipStream_t s);
-hipError_t ik_launch_select(const IkBatchArgs &a, int cap, hipStream_t s);
+hipError_t ik_launch_select(const IkBatchArgs &a, int cap, int force, hipStream_t s);   // force: tests (take the lane whatever the batch looks like)
 hipError_t ik_launch_fused_express(const IkBatchArgs &a, int cap, hipStream_t side);
 hipError_t ik_launch_fused_tail(const IkBatchArgs &a, hipStream_t s);
 // centroidal state [com, vcom, L] (9) of (q, v): KinoDynMP::optimize's x0 (kino_dyn.cpp:42,86-97)

@@ -223,7 +223,8 @@ typedef struct {
     int express_cap;        /* NOT a threshold: the most problems the express lane may take off the batch (bmpc_ik_set_express_capacity;
                                0 = the process default, < 0 = no express lane) */
     int debug_inject;       /* tests only: 1 = overwrite the first active-list entry with an out-of-range index right after the
-                               list is initialised; the solve must then return BMPC_DEVICE_ERROR (index checks of the list code) */
+                               list is initialised; the solve must then return BMPC_DEVICE_ERROR (index checks of the list code);
+                               2 = the express lane takes its problems in front of iteration 2 whatever the batch looks like */
 } bmpc_ik_sched_t;
 typedef struct {
     int B, n_col, maxiter;

@@ -431,3 +431,54 @@ def test_express_lane_does_not_change_results(model):
     for i in np.where(took)[0][:6]:                  # ... the per-iteration trace too: same accepted step lengths, same regularisation
         assert np.array_equal(on["ik_trace"][i, :n[i]], off["ik_trace"][i, :n[i]]), i
     assert np.all(on["ik_fused_iters"][took] <= n[took]) and np.all(on["ik_fused_iters"][took] >= n[took] - 6)
+
+
+def test_fused_kernel_on_the_long_horizon_and_through_regularisation_restarts():
+    """The persistent fused kernel where the express lane's own rule never sends it: forced onto the synthetic Go2 H = 60 /
+    H_ik = 30 batch from iteration 2 (31 nodes: the producer waves run sixteen pairs ahead of the recursion, problems take
+    partial steps, second rounds of step lengths and up to SolverDDP's 100 iterations) -- and, on Solo12, onto problems whose
+    first Riccati pass fails on a pivot and restarts at a larger regularisation inside the kernel.  Every bit of every result as
+    without the lane."""
+    import dataclasses
+    from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
+    robots = os.path.dirname(ROBOT)
+    go2 = urdf_model.RobotModel.from_json(open(os.path.join(robots, "go2.json")).read())
+    wb = problems.make_wb_batch(go2, 192, gait=dataclasses.replace(problems.TROT, nom_ht=0.30, gait_horizon=6.0), wb=problems.GO2_WB)
+    out = {}
+    for name, sched in (("off", {"express_cap": -1}), ("forced", {"express_cap": 24, "debug_inject": 2})):
+        kb = KinoDynDeviceBatch(wb, go2, num_iters=10, schedule=sched)
+        kb.solve()
+        out[name] = kb.results()
+    off, on = out["off"], out["forced"]
+    took = on["ik_fused_iters"] > 0
+    print("Go2 H_ik=30: the forced lane took %d problems, iterations %s" % (took.sum(), sorted(on["ik_iters"][took].tolist())))
+    assert took.sum() == 24 and on["ik_iters"][took].max() >= 60
+    for k in ("xs", "us", "ik_cost", "ik_stop", "ik_iters", "ik_status"):
+        assert np.array_equal(on[k], off[k]), k
+    n = on["ik_iters"]
+    for i in np.where(took)[0]:
+        assert np.array_equal(on["ik_trace"][i, :min(n[i], 128)], off["ik_trace"][i, :min(n[i], 128)]), i
+    assert np.any(on["ik_trace"][took][:, :, 2][on["ik_trace"][took][:, :, 2] > 0] < 1.0)      # partial steps were taken inside the kernel
+
+
+def test_fused_kernel_restarts_its_riccati_pass(model):
+    """heavy state-regularisation-free problems whose first backward pass hits a non-positive pivot: the restart (regularisation
+    x 10, same derivatives) happens inside the fused kernel's tick loop"""
+    from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
+    wb = problems.make_wb_batch(model, 128)
+    wb.ik_tasks[:, :, 31] = 0.0          # no state regularisation: Q_uu of the first pass is not positive definite
+    out = {}
+    for name, sched in (("off", {"express_cap": -1}), ("forced", {"express_cap": 16, "debug_inject": 2})):
+        kb = KinoDynDeviceBatch(wb, model, num_iters=10, ddp_maxiter=30, schedule=sched)
+        kb.solve()
+        out[name] = kb.results()
+    off, on = out["off"], out["forced"]
+    took = on["ik_fused_iters"] > 0
+    reg = off["ik_trace"][:, :, 1]
+    print("forced lane took %d problems; largest regularisation along the way %.1e; statuses %s" % (took.sum(), reg.max(), np.unique(on["ik_status"]).tolist()))
+    assert took.sum() == 16
+    for k in ("xs", "us", "ik_cost", "ik_iters", "ik_status"):
+        assert np.array_equal(on[k], off[k]), k
+    n = on["ik_iters"]
+    for i in np.where(took)[0]:
+        assert np.array_equal(on["ik_trace"][i, :n[i]], off["ik_trace"][i, :n[i]]), i
