@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 judged artefacts (GPU box, repo root): tools/prof_round2.sh <tag>
+# Judged artefacts of a round (GPU box, repo root): tools/prof_round2.sh <tag>   (rounds 2 and 3)
 #  1. default bench line under rocprofv3 --kernel-trace --stats
 #  2. HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes, counters only with --kernel-trace) of the headline kernel and of
 #     every kernel of the two KinoDyn workloads
