@@ -9,7 +9,10 @@ IK-DDP; BASELINE config 5's shape with `--kinodyn-config go2_h60`) the measured 
 
 Multi-GPU: one process per GPU, every leg shards its batch (rank r solves problems [r*B, (r+1)*B)), no data-path
 collective (the solves are independent); RCCL only carries the timing / telemetry reductions.  Every leg is bracketed by a
-barrier + synchronize on both sides and reports the MAX over ranks.
+barrier + synchronize on both sides and reports the MAX over ranks.  Under a launcher (the driver's torch.distributed.run line)
+the ranks come from RANK / WORLD_SIZE; a plain `python bench.py --gpus N` starts that launcher itself, before this process
+touches the GPU, and passes rank 0's line through.  At N = 1 RCCL is brought up with one rank as well (`rccl` in the line), so the
+barriers and reductions of the N > 1 path run on every bench.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with
   roofline      HBM view of the dominant kernel (algorithmic bytes / measured kernel time; the path is fp64-VALU / latency

@@ -7,26 +7,35 @@
 // crocoddyl::SolverDDP::solve() with all defaults.  crocoddyl 1.9.0 / pinocchio 2.6.9 are third
 // party and absent: semantics follow oracle/ik_ddp_np.py (PARITY UNPINNED).
 //
-// MI355X organisation (nothing like crocoddyl's object graph): four kernels per DDP iteration over the problems still
-// iterating (an active list the forward pass rebuilds), all per-problem state in one contiguous HBM workspace (IkLayout):
-//   ik_state_kernel     one LANE per (problem, node): the scalar chains of the derivative pass (state residual with its Jlog6
-//                       block, Euler step with its Jintegrate blocks, node cost parts) ahead of ik_calcdiff_kernel.
-//   ik_calcdiff_kernel  TWO waves per (problem, node): wave 0 walks the robot once (lane = velocity column, part sums
-//                       through LDS), wave 1 does the state residual / Euler step Jacobians meanwhile; both then
-//                       assemble the Gauss-Newton L_x / L_xx by column (coalesced 10 KB store).
-//   ik_backward_kernel  one WAVE per problem, matrix rows in registers (lane r = row r of V, G, Q_xx), exploiting
-//                       F_x = [[A, dt B],[0, I]], F_u = dt F_x[:, v] (A, B identity except a 6x6 free-flyer block):
-//                       G = F_x^T V F_x via one LDS transposition, Cholesky in registers over v_readlane, the gain
-//                       solves against broadcast LDS reads, V_xx = Q_xx - Y^T Y on the matrix pipe; regularisation retries
-//                       inside the kernel (details above the kernel).  <2>: a second wave per problem computes and stores
-//                       the gains one node behind the recursion (few problems left).
-//   ik_forward_kernel   FOUR problems per wave (16 lanes each), or four step lengths of one problem with a second wave for
-//                       the cost side (and a third for the state regularisation) when few problems are left, all ten on three
-//                       workgroups for the problems flagged as needing them: line search 2^-k, k = 0..9 -- feedback
-//                       u = u - a k - K dx, node evaluation spread over the sub-group's lanes (legs, base, state
-//                       cost, control cost + Euler step); acceptance, regularisation update and stopping test
-//                       as crocoddyl 1.9.0 solver-ddp.cpp.
-// The host loops over DDP iterations and stops when the device-side active counter reaches zero.
+// MI355X organisation (nothing like crocoddyl's object graph).  All per-problem state lives in one contiguous HBM workspace
+// (IkLayout); the DEVICE PIECES below are shared by every mapping, so a problem's result never depends on how it was scheduled
+// (the tests compare bit for bit):
+//   state_node          the scalar chains of a node's derivative pass (state residual with its Jlog6 block, Euler step with its
+//                       Jintegrate blocks, node cost parts): one LANE per (problem, node)  [ik_state_kernel]
+//   calc_walk / calc_columns / calc_assemble
+//                       one robot walk per node (lane = velocity column, part sums through LDS), the residual Jacobian's
+//                       columns, the Gauss-Newton L_x / L_xx (3 x 3 tiles of v_mfma_f64_16x16x4)
+//                       [ik_calcdiff_kernel: two waves per node pair; ik_calcdiff1_kernel: ONE wave per pair when a launch has
+//                       more pairs than the chip holds]
+//   backward_main_wave (+ backward_gains_wave)
+//                       one WAVE per problem, matrix rows in registers (lane r = row r of V, G, Q_xx), exploiting
+//                       F_x = [[A, dt B],[0, I]], F_u = dt F_x[:, v-columns]: G = F_x^T V F_x via one LDS transposition,
+//                       Cholesky in registers over v_readlane with the forward substitutions riding along, V_xx = Q_xx - Y^T Y
+//                       on the matrix pipe, regularisation retries inside; with few problems a second wave computes and stores
+//                       the gains one node behind  [ik_backward_kernel<1|2>]
+//   forward_body<NW, FUSED, ROLES>
+//                       line search 2^-k + rollout: FOUR problems per wave, or four step lengths of one problem on two / three
+//                       waves, each wave a separately compiled instantiation of its role (chain / robot walks / state
+//                       residual); all ten step lengths on three workgroups for the problems flagged as needing them;
+//                       acceptance, regularisation update and stopping test as crocoddyl 1.9.0 solver-ddp.cpp
+//                       [ik_forward_kernel<1|2|3>]
+// Two ways of running them:
+//   * LOCK-STEP: four launches per DDP iteration over the problems still iterating (an active list the forward pass rebuilds);
+//     the host loops and stops when the device-side counter reaches zero (bunmpc_ik_capi.hip::run_ddp);
+//   * FUSED: ik_fused_kernel, one persistent four-wave workgroup per problem running whole DDP iterations on chip with no host
+//     look (derivative pass pipelined behind the Riccati pass over shared barrier "ticks", then the line search), fed by the
+//     EXPRESS LANE: ik_select_kernel takes the problems farthest from converging off a fast-converging batch after its third
+//     iteration, and they run to the end on a side stream while the batch goes on without them.
 #include "ik_types.h"
 #include "rbd_quad.h"
 #include "lds_batch.h"
