@@ -1632,71 +1632,77 @@ __device__ __forceinline__ IkBatchArgs uniform_args(const IkBatchArgs &g) {
 __device__ __forceinline__ IkBatchArgs fused_args() { return uniform_args(g_fused.args); }
 
 // Producer wave p (0 / 1) of the fused kernel: node pairs p, p + 2, ... counted from the terminal node down (pair j = nodes
-// T - 2j, T - 2j - 1), two ticks per pair -- [stage, walk, columns] [state terms in, assemble A, assemble B] -- so the two of them
-// deliver two nodes per tick against the recursion's one; producer 1 spends its first tick on the scalar chains of every node
-// (one lane per node).  Walk and columns share a tick because the walk's per-lane state must reach the columns in REGISTERS, as it
-// does in ik_calcdiff_kernel: parked in LDS in between (tried: shorter ticks) the compiler can no longer contract a product of
-// the walk into a sum of the columns, and the node derivatives differ in their last bits from the multi-kernel path's; carried in
-// registers around the loop's barrier hipcc spills it.
+// T - 2j, T - 2j - 1), three ticks per pair -- [stage, walk] [columns, state terms in, assemble A] [assemble B] -- each shorter than
+// a node of the recursion, which then never waits for a producer at a tick (with walk and columns in one tick of 23K cycles it
+// did, 5K cycles per node: measured with idle producers); together the producers deliver four nodes per three ticks against the
+// recursion's one per tick.  Producer 1 spends its first tick on the scalar chains of every node (one lane per node).  The
+// walk's per-lane state reaches the columns in REGISTERS, as in ik_calcdiff_kernel (parked in LDS in between, the compiler can no
+// longer contract a product of the walk into a sum of the columns and the derivatives differ in their last bits from the
+// multi-kernel path's), and the pair's three steps are STRAIGHT-LINE code around their ticks: as states of a loop around one
+// barrier, hipcc carried that state across the back edge in scratch.
 __device__ __forceinline__ void producer_wave(const IkBatchArgs &a, long b, FusedLds &s, int p, int lane, Ticker &tk) {
     FusedCtl &ctl = s.ctl;
     const int stamp = ctl.stamp, T = a.T, nn = T + 1, npairs = (nn + 1) / 2;
     const IkLayout L = IkLayout::make(T);
     double *ws = a.ws + b * L.total;
+#ifdef FUSED_NO_PRODUCE     // timing experiment only (wrong results): the producers do nothing, the derivatives of the lock-step iterations stay
+    const bool recalc = false;
+#else
     const bool recalc = ws[L.scal + S_RECALC] != 0.0;
+#endif
     const RobotModelDev &m = s.fw.m;
     const double *state_w0 = batch_ptr(a.state_w, a.s_state_w, b), *ctrl_w0 = batch_ptr(a.ctrl_w, a.s_ctrl_w, b);
     const int hs = lane >> 5, hl = lane & 31;
     CalcNode &qw = s.nd[p][hs];
-    int pair = p, phase = p == 1 ? 0 : 1;
-    bool first = true;
     // A flag is raised only once the global stores it stands for have completed: the recursion reads flags in the middle of ticks
     // too (whether node t - 1 can be requested a node ahead), not only right behind the barrier that follows the producer's step.
     auto stores_done = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-    for (;;) {
-        if (!recalc) {
-            // the line search of the iteration before accepted nothing: the derivatives in the workspace are still those of this trajectory
-            if (first && p == 0) { if (lane <= T) ctl.ready[lane] = stamp; if (lane == 0) ctl.state_ready = stamp; }
-        } else if (phase == 0) {
+    // one tick; true when the phase is over (or the watchdog fired): the caller returns at once, with no further barrier
+    auto tick_over = [&]() -> bool { tick_mem(tk); return tk.dead || tk.n >= lds_flag(ctl.done_tick); };
+    if (!recalc) {
+        // the line search of the iteration before accepted nothing: the derivatives in the workspace are still those of this trajectory
+        if (p == 0) { if (lane <= T) ctl.ready[lane] = stamp; if (lane == 0) ctl.state_ready = stamp; }
+    } else {
+        if (p == 1) {
             if (lane <= T) state_node(a, b, lane, ws, L);
             stores_done();
             if (lane == 0) ctl.state_ready = stamp;
-            phase = 1;
-        } else if (pair < npairs) {
+            if (tick_over()) return;
+        }
+        for (int pair = p; pair < npairs; pair += 2) {
             const int tA = T - 2 * pair, tB = tA - 1, tw = hs == 0 ? tA : tB;
             const bool wvalid = tw >= 0;
-            if (phase == 1) {
-                UNROLL_RBD for (int h = 0; h < kCalcNodes; ++h) {
-                    const int t = h == 0 ? tA : tB;
-                    if (t >= 0) {
-                        CalcNode &q = s.nd[p][h];
-                        if (lane < kNX) q.x[lane] = ws[L.xs + (long)t * kNX + lane];
-                        if (lane < kNV) q.u[lane] = t == T ? 0.0 : ws[L.us + (long)t * kNV + lane];
-                    }
+            UNROLL_RBD for (int h = 0; h < kCalcNodes; ++h) {
+                const int t = h == 0 ? tA : tB;
+                if (t >= 0) {
+                    CalcNode &q = s.nd[p][h];
+                    if (lane < kNX) q.x[lane] = ws[L.xs + (long)t * kNX + lane];
+                    if (lane < kNV) q.u[lane] = t == T ? 0.0 : ws[L.us + (long)t * kNV + lane];
                 }
-                wave_sync();
-                NodeTasks tkw{a.tasks + (b * nn + (wvalid ? tw : tA)) * kNodeTaskDoubles};
-                PartWalk pw;
-                double Rb[9], pb[3], Vb[6];
-                if (wvalid && hl < kNV) calc_walk(m, qw, tkw, hl, Rb, pb, Vb, pw);
-                wave_sync();
-                if (wvalid && hl < kNV) calc_columns(m, qw, tkw, hl, pw);
-                phase = 2;
-            } else {
-                // (the scalar chains of these nodes are there: they take producer 1's first tick, and this is tick 2 at the earliest)
-                if (wvalid) calc_fetch_state(qw, ws, L, tw, hl);
-                wave_sync();
-                calc_assemble(a, b, tA, s.nd[p][0], ws, L, lane, state_w0, ctrl_w0, &ctl.node_cost[tA]);
-                if (tB >= 0) calc_assemble(a, b, tB, s.nd[p][1], ws, L, lane, state_w0, ctrl_w0, &ctl.node_cost[tB]);
+            }
+            wave_sync();
+            NodeTasks tkw{a.tasks + (b * nn + (wvalid ? tw : tA)) * kNodeTaskDoubles};
+            PartWalk pw;
+            double Rb[9], pb[3], Vb[6];
+            if (wvalid && hl < kNV) calc_walk(m, qw, tkw, hl, Rb, pb, Vb, pw);
+            if (tick_over()) return;
+            // (the scalar chains of these nodes are there: they take producer 1's first tick, and this is tick 2 at the earliest)
+            if (wvalid) calc_fetch_state(qw, ws, L, tw, hl);
+            if (wvalid && hl < kNV) calc_columns(m, qw, tkw, hl, pw);
+            wave_sync();
+            calc_assemble(a, b, tA, s.nd[p][0], ws, L, lane, state_w0, ctrl_w0, &ctl.node_cost[tA]);
+            stores_done();
+            if (lane == 0) ctl.ready[tA] = stamp;
+            if (tick_over()) return;
+            if (tB >= 0) {
+                calc_assemble(a, b, tB, s.nd[p][1], ws, L, lane, state_w0, ctrl_w0, &ctl.node_cost[tB]);
                 stores_done();
-                if (lane == 0) { ctl.ready[tA] = stamp; if (tB >= 0) ctl.ready[tB] = stamp; }
-                phase = 1; pair += 2;
+                if (lane == 0) ctl.ready[tB] = stamp;
+                if (tick_over()) return;
             }
         }
-        first = false;
-        tick_mem(tk);
-        if (tk.dead || tk.n >= lds_flag(ctl.done_tick)) return;
     }
+    for (;;) { if (tick_over()) return; }      // everything produced: ticks until the phase is over
 }
 
 // the roles: each returns the ticks it counted, or -1 when the watchdog fired (every wave counts the same barriers)
