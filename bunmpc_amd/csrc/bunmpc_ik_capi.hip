@@ -202,8 +202,11 @@ struct ActiveWord {
         // kernels instead of beside them (seen in bench.py, whose process holds a dozen streams: 19.8 ms per batch solve instead
         // of 15.1); queues are per priority level, and the lane's workgroups should be placed first anyway.
         int pr_least = 0, pr_greatest = 0;
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
-        HIP_TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, pr_greatest));
+        if (hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest) != hipSuccess ||
+            hipStreamCreateWithPriority(&side, hipStreamNonBlocking, pr_greatest) != hipSuccess) {
+            (void)hipGetLastError();        // no priorities on this runtime: an ordinary stream still gives correct results
+            HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        }
         HIP_TRY(hipEventCreateWithFlags(&x_go, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&x_done, hipEventDisableTiming | hipEventBlockingSync));
         return BMPC_OK;

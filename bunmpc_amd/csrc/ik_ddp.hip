@@ -709,17 +709,26 @@ struct Ticker {
     long long wait = 0;     // telemetry: cycles spent at the tick barriers
 };
 // the recursion's and the gains wave's barrier: LDS traffic complete (their hand-over goes through LDS)
+// (-DFUSED_TELEMETRY: cycles spent at the barriers, per wave -- two s_memtime and their waits per tick, so not in the product build)
 __device__ __forceinline__ void tick_lds(Ticker &tk) {
+#ifdef FUSED_TELEMETRY
     const long long t0 = __builtin_readcyclecounter();
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef FUSED_TELEMETRY
     tk.wait += (long long)__builtin_readcyclecounter() - t0;
+#endif
     if (++tk.n > tk.limit) tk.dead = true;
 }
 // the producers' barrier: their global stores (the node derivatives) complete as well
 __device__ __forceinline__ void tick_mem(Ticker &tk) {
+#ifdef FUSED_TELEMETRY
     const long long t0 = __builtin_readcyclecounter();
+#endif
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef FUSED_TELEMETRY
     tk.wait += (long long)__builtin_readcyclecounter() - t0;
+#endif
     if (++tk.n > tk.limit) tk.dead = true;
 }
 __device__ __forceinline__ int lds_flag(const int &f) { return *const_cast<const volatile int *>(&f); }
