@@ -179,6 +179,7 @@ _SIGS = {
     "bmpc_ik_set_gains_wave_below": (_I, [_I]),
     "bmpc_ik_set_blocking_waits": (_I, [_I]),
     "bmpc_ik_set_express_capacity": (_I, [_I]),
+    "bmpc_ik_set_fused_direct_max": (_I, [_I]),
     "bmpc_ik_set_express_near": (C.c_double, [C.c_double]),
     "bmpc_ik_batch_struct_size": (_I, []),
     "bmpc_ik_active_list_ints": (C.c_long, [C.c_long]),

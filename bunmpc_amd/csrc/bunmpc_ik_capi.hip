@@ -141,6 +141,12 @@ int pack_tasks(const bmpc_ik *h, std::vector<double> &tasks) {
     return BMPC_OK;
 }
 
+// the pieces of the scratch behind bmpc_ik_batch_t.active_list (ik_types.h::active_list_ints)
+void set_list(bunmpc::IkBatchArgs &a, int *p) {
+    using namespace bunmpc;
+    a.list = p; a.count = a.list + 2 * (long)a.B; a.wcount = a.count + 2; a.wide = a.wcount + 2; a.err = a.wide + 2 * kWideMax;
+    a.near = a.err + 2; a.xmeta = a.near + 2; a.xlist = a.xmeta + 4;
+}
 std::atomic<double> g_express_near{1.0};   // the express lane's trigger: |Q_u|^2 below this = "within reach of the stopping threshold"
 
 bunmpc::IkBatchArgs make_args(int B, int T, int maxiter, const bmpc_model *model, const double *x0, const double *dt,
@@ -172,10 +178,11 @@ std::atomic<int> g_blocking_waits{1};       // the DDP loop's host waits sleep o
 constexpr int kMaxIkCol = 63;     // T + 1 <= 64 nodes: the backward pass computes the gaps one lane per node
 
 // thresholds of ONE DDP loop: field of bmpc_ik_batch_t.sched (0 = the process default, < 0 = never, n > 0 = n)
-struct Sched { int spec_below, all_steps, gains_wave_below; int debug_inject = 0; int express_cap = 0; };
+struct Sched { int spec_below, all_steps, gains_wave_below; int debug_inject = 0; int express_cap = 0; int fused_direct = 0; };
 int sched_pick(int field, const std::atomic<int> &dflt) { return field == 0 ? dflt.load() : field < 0 ? 0 : field; }
 std::atomic<int> g_express_cap{96};         // the express lane takes at most this many problems of a batch (0 = no express lane)
-Sched default_sched() { return Sched{g_spec_line_search_below.load(), g_all_steps.load(), g_gains_wave_below.load(), 0, g_express_cap.load()}; }
+std::atomic<int> g_fused_direct{16};        // batches of at most this many problems run entirely inside the fused kernel (0 = never)
+Sched default_sched() { return Sched{g_spec_line_search_below.load(), g_all_steps.load(), g_gains_wave_below.load(), 0, g_express_cap.load(), g_fused_direct.load()}; }
 
 // Two host-mapped words and events per (device, stream), through which the kernels' active counter reaches the DDP loop.
 // Keyed by the stream, not by the host thread: a stream's publishes are ordered among themselves, so a late publish of one
@@ -232,6 +239,13 @@ bool g_profile = false;
 double g_last_profile[5] = {0, 0, 0, 0, 0};     // ms: state, calcdiff, backward, forward, everything else in the loop
 std::mutex g_profile_lock;
 
+int index_check_failed(int code) {
+    static const char *what[] = {"", "active-list entry out of range", "active-list length out of range", "active-list append past its end",
+                                 "wide-list entry out of range", "the fused kernel's tick watchdog fired"};
+    return ik_fail(BMPC_DEVICE_ERROR, std::string("IK-DDP index check failed: ") + what[code > 0 && code < 6 ? code : 0] +
+                   " (code " + std::to_string(code) + "); results of this batch are invalid");
+}
+
 int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run, const Sched sched) {
     bunmpc::IkBatchArgs a = a0;
     a.fwd_spec = 0;
@@ -253,6 +267,20 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run, const
     hipEvent_t *ev = w.evs[g_blocking_waits.load() ? 1 : 0];
     HIP_TRY(bunmpc::ik_launch_init(a, st));
     if (sched.debug_inject == 1 && a.list) HIP_TRY(hipMemsetAsync(a.list, 0x7f, sizeof(int), st));      // tests: an entry far out of range
+    // A handful of problems (the single-problem handles of the drop-in classes above all): every one of them gets a CU of its own
+    // from the first iteration on -- the whole DDP in ONE launch of the fused kernel, no host look in between.
+    if (a.list && a.B <= sched.fused_direct && a.maxiter > 0) {
+        a.iter = 0; a.n_launch = a.B;
+        HIP_TRY(bunmpc::ik_launch_fused_tail(a, st));
+        HIP_TRY(bunmpc::ik_launch_publish_active(a, 0, w.dev[0], st));
+        HIP_TRY(hipEventRecord(ev[0], st));
+        HIP_TRY(hipEventSynchronize(ev[0]));
+        const volatile int *hw = static_cast<volatile int *>(w.host[0]);
+        if (iters_run) *iters_run = a.maxiter;
+        if (hw[1]) return index_check_failed(hw[1]);
+        if (hw[0] != 0) return ik_fail(BMPC_DEVICE_ERROR, "the fused kernel left problems unsolved");
+        return BMPC_OK;
+    }
     // The host looks at the active counter after every iteration while many problems are iterating (iterations are long
     // there and the line-search mapping depends on it); once few are left it enqueues kTailChunk iterations per look --
     // kernels of a finished problem return at once, so an iteration too many costs a few microseconds.  And it looks
@@ -334,12 +362,7 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run, const
         all_active = hw[0];
         if (!index_err) index_err = hw[1];
     }
-    if (index_err) {
-        static const char *what[] = {"", "active-list entry out of range", "active-list length out of range", "active-list append past its end",
-                                     "wide-list entry out of range", "the fused kernel's tick watchdog fired"};
-        return ik_fail(BMPC_DEVICE_ERROR, std::string("IK-DDP index check failed: ") + what[index_err < 6 ? index_err : 0] +
-                       " (code " + std::to_string(index_err) + "); results of this batch are invalid");
-    }
+    if (index_err) return index_check_failed(index_err);
     if (prof && !pev.empty()) {
         HIP_TRY(hipEventSynchronize(pev.back()));
         double acc[5] = {0, 0, 0, 0, 0};
@@ -508,6 +531,7 @@ int bmpc_ik_selftest_state_ops(const double *x0, const double *x1, const double 
 int bmpc_ik_set_all_steps(int n_active) { return g_all_steps.exchange(n_active); }
 int bmpc_ik_set_blocking_waits(int on) { return g_blocking_waits.exchange(on != 0); }
 int bmpc_ik_set_express_capacity(int n) { return g_express_cap.exchange(n); }
+int bmpc_ik_set_fused_direct_max(int n) { return g_fused_direct.exchange(n); }
 double bmpc_ik_set_express_near(double stop) { return g_express_near.exchange(stop); }
 int bmpc_ik_batch_struct_size(void) { return (int)sizeof(bmpc_ik_batch_t); }
 int bmpc_ik_set_speculative_below(int n_active) { return g_spec_line_search_below.exchange(n_active); }
@@ -654,12 +678,13 @@ int bmpc_ik_optimize(bmpc_ik_t *h, const double *x0) {
                  o_sw = push(sw.data(), sw.size()), o_xr = push(xr.data(), xr.size()), o_cw = push(cw.data(), cw.size());
     HIP_TRY(h->din.ensure(sizeof(double) * stage.size()));
     HIP_TRY(h->dws.ensure(sizeof(double) * (size_t)L.total));
-    HIP_TRY(h->dactive.ensure(sizeof(int)));
+    HIP_TRY(h->dactive.ensure(sizeof(int) * (1 + active_list_ints(1))));     // the counter + a one-problem active list (index checks, fused kernel)
     HIP_TRY(hipMemcpy(h->din.p, stage.data(), sizeof(double) * stage.size(), hipMemcpyHostToDevice));
     const double *d = h->din.d();
     IkBatchArgs a = make_args(1, T, 100, model, d + o_x0, d + o_dt, d + o_tk, d + o_sw, 0, d + o_xr, d + o_cw, 0, h->dws.d(),
                               static_cast<int *>(h->dactive.p));
     a.sn_state_w = kNDX; a.sn_x_reg = kNX; a.sn_ctrl_w = kNV;
+    set_list(a, static_cast<int *>(h->dactive.p) + 1);
     if (int rc = run_ddp(a, nullptr, nullptr, default_sched())) return rc;
     h->xs.resize((size_t)nn * kNX); h->us.resize((size_t)T * kNV);
     double scal[16];
@@ -721,11 +746,11 @@ int bmpc_ik_solve_batch_device(const bmpc_ik_batch_t *d, void *hip_stream) {
                               d->ctrl_w, d->s_ctrl_w, d->ws, d->active);
     a.s_x_reg = d->s_x_reg ? d->s_x_reg : kNX;
     a.sn_state_w = d->sn_state_w; a.sn_x_reg = d->sn_x_reg; a.sn_ctrl_w = d->sn_ctrl_w;
-    if (d->active_list) { a.list = d->active_list; a.count = a.list + 2 * (long)d->B; a.wcount = a.count + 2; a.wide = a.wcount + 2; a.err = a.wide + 2 * kWideMax;
-                          a.near = a.err + 2; a.xmeta = a.near + 2; a.xlist = a.xmeta + 4; }
+    if (d->active_list) set_list(a, d->active_list);
     int iters = 0;
     const Sched sched{sched_pick(d->sched.spec_below, g_spec_line_search_below), sched_pick(d->sched.all_steps_below, g_all_steps),
-                      sched_pick(d->sched.gains_wave_below, g_gains_wave_below), d->sched.debug_inject, sched_pick(d->sched.express_cap, g_express_cap)};
+                      sched_pick(d->sched.gains_wave_below, g_gains_wave_below), d->sched.debug_inject, sched_pick(d->sched.express_cap, g_express_cap),
+                      g_fused_direct.load()};
     int rc = run_ddp(a, static_cast<hipStream_t>(hip_stream), &iters, sched);
     if (d->iters_run) *d->iters_run = iters;
     return rc;

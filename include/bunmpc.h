@@ -270,6 +270,10 @@ int bmpc_ik_set_blocking_waits(int on);
  * host look) runs them to the end on a side stream while the batch goes on without them.  Default 96; 0 = no express lane.
  * Returns the old value. */
 int bmpc_ik_set_express_capacity(int n);
+/* Batches of at most n problems (the single-problem handles InverseKinematics / KinoDynMP above all) run their whole DDP in ONE
+ * launch of the fused kernel, every problem on a CU of its own, with no host look between iterations (no effect on results).
+ * Default 16; 0 = never.  Returns the old value. */
+int bmpc_ik_set_fused_direct_max(int n);
 /* ... and what "near the stopping threshold" means in that trigger: |Q_u|^2 < stop at the problem's last Riccati pass (SolverDDP
  * stops below 1e-9).  Default 1.0.  Returns the old value. */
 double bmpc_ik_set_express_near(double stop);

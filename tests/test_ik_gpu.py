@@ -214,6 +214,7 @@ def test_line_search_scheduling_does_not_change_results(model):
     wb = problems.make_wb_batch(model, 9)
     out = []
     old, old_all, old_gw = lib.bmpc_ik_set_speculative_below(0), lib.bmpc_ik_set_all_steps(0), lib.bmpc_ik_set_gains_wave_below(0)
+    old_fd = lib.bmpc_ik_set_fused_direct_max(0)       # (a batch this small would otherwise never see the multi-kernel path)
     try:
         for below, all_steps, use_list, gains in ((0, 0, True, 0), (1 << 30, 0, True, 0), (1 << 30, 1 << 30, True, 1 << 30), (0, 0, False, 1 << 30),
                                                   (1 << 30, 1 << 30, False, 0), (6, 3, True, 4)):
@@ -223,10 +224,16 @@ def test_line_search_scheduling_does_not_change_results(model):
             kb = KinoDynDeviceBatch(wb, model, num_iters=10, use_active_list=use_list)
             kb.solve()
             out.append(kb.results())
+        lib.bmpc_ik_set_fused_direct_max(16)           # ... and the whole batch inside the persistent fused kernel
+        kb = KinoDynDeviceBatch(wb, model, num_iters=10)
+        kb.solve()
+        out.append(kb.results())
+        assert np.all(out[-1]["ik_fused_iters"] == out[-1]["ik_iters"]) and not np.any(out[0]["ik_fused_iters"])
     finally:
         lib.bmpc_ik_set_speculative_below(old)
         lib.bmpc_ik_set_all_steps(old_all)
         lib.bmpc_ik_set_gains_wave_below(old_gw)
+        lib.bmpc_ik_set_fused_direct_max(old_fd)
     assert np.all(out[0]["ik_status"] == 0) and len(set(out[0]["ik_iters"].tolist())) > 1      # problems finish at different iterations
     for o in out[1:]:
         assert np.array_equal(out[0]["ik_iters"], o["ik_iters"])
@@ -284,16 +291,23 @@ def test_riccati_pass_that_fails_and_restarts(model):
     sw[0, 24:30] = -40.0         # leg joint velocities rewarded instead of penalised
     wb = dataclasses.replace(wb, state_w=sw)
     out = []
-    old_gw = lib.bmpc_ik_set_gains_wave_below(0)
+    old_gw, old_fd = lib.bmpc_ik_set_gains_wave_below(0), lib.bmpc_ik_set_fused_direct_max(0)
     try:
         for gains in (0, 1 << 30):
             lib.bmpc_ik_set_gains_wave_below(gains)
             kb = KinoDynDeviceBatch(wb, model, num_iters=10)
             kb.solve()
             out.append(kb.results())
+        lib.bmpc_ik_set_fused_direct_max(16)           # the same restarts inside the fused kernel's tick loop
+        kb = KinoDynDeviceBatch(wb, model, num_iters=10)
+        kb.solve()
+        fused = kb.results()
     finally:
         lib.bmpc_ik_set_gains_wave_below(old_gw)
+        lib.bmpc_ik_set_fused_direct_max(old_fd)
     a, b = out
+    for k in ("ik_iters", "ik_status", "xs", "us", "ik_cost", "ik_stop"):
+        assert np.array_equal(fused[k], a[k]), k
     n = a["ik_iters"]
     reg = [a["ik_trace"][i, :n[i], 1] for i in range(6)]
     assert any((r[1:] > 5 * r[:-1]).any() for r in reg if len(r) > 1) or (a["ik_status"] == 2).any()     # the regularisation did go up
@@ -348,8 +362,18 @@ def test_ik_longest_horizon(model):
 IK_GOLDEN = sorted(__import__("glob").glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ik_*.npz")))
 
 
+@pytest.fixture(params=["fused", "lockstep"])
+def small_batch_path(request):
+    """batches of <= 16 problems run entirely inside the fused kernel by default (bmpc_ik_set_fused_direct_max); the multi-kernel
+    path must give the same answers on them"""
+    from bunmpc_amd import _lib
+    old = _lib.lib().bmpc_ik_set_fused_direct_max(16 if request.param == "fused" else 0)
+    yield request.param
+    _lib.lib().bmpc_ik_set_fused_direct_max(old)
+
+
 @pytest.mark.parametrize("path", IK_GOLDEN, ids=[os.path.basename(p)[:-4] for p in IK_GOLDEN])
-def test_ik_golden_fixtures(path):
+def test_ik_golden_fixtures(path, small_batch_path):
     """Committed inputs / outputs of the whole-body DDP (tests/golden/make_golden_ik.py: four Solo12 problems, three synthetic-Go2
     H = 60 / H_ik = 30 problems of which one runs to SolverDDP's maxiter), fed to bmpc_ik_solve_batch_device as the arrays the
     file holds -- no oracle build, no problem generator between the fixture and the kernels.  The GPU must take the committed

@@ -61,17 +61,24 @@ def _go2_wb(B, first=0):
     return go2, wb
 
 
-def test_ddp_problems_that_hit_maxiter_follow_the_cpu_twin():
+@pytest.mark.parametrize("fused_direct", [16, 0], ids=["fused", "lockstep"])
+def test_ddp_problems_that_hit_maxiter_follow_the_cpu_twin(fused_direct):
     """Problems 2, 13 and 14 of the bench's Go2 H = 60 batch never reach SolverDDP's stopping threshold (|Q_u|^2 < 1e-9) within
     its 100 iterations.  Not a regularisation limit cycle: the regularisation stays at its floor (1e-9) and the cost falls
     monotonically -- the Gauss-Newton DDP converges linearly with partial steps (alpha 1/16 ... 1/2) on these plans and simply
     runs out of iterations (EXPERIMENTS.md 9).  GPU and CPU twin must agree on every discrete decision along the way."""
     from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
     from oracle import ik_oracle_c as ic
+    from bunmpc_amd import _lib
     go2, wb = _go2_wb(16)
     kb = KinoDynDeviceBatch(wb, go2, num_iters=10)
-    kb.solve()
+    old = _lib.lib().bmpc_ik_set_fused_direct_max(fused_direct)     # 16: the whole batch inside the fused kernel; 0: the multi-kernel path
+    try:
+        kb.solve()
+    finally:
+        _lib.lib().bmpc_ik_set_fused_direct_max(old)
     g = kb.results()
+    assert np.all(g["ik_fused_iters"] > 0) == (fused_direct > 0)
     r = ic.solve_wb_batch(ic.Model(go2), wb, g["X"], trace=True)
     long_runs = np.where(r["status"] == 1)[0]
     assert len(long_runs) >= 3 and {2, 13, 14} <= set(long_runs.tolist())
