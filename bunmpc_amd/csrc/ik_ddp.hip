@@ -695,7 +695,6 @@ struct FusedCtl {
     int hand_count;         // nodes (and end markers) the recursion has handed to the gains wave in this phase
     int done_tick;          // the phase ends with the tick of this number (INT_MAX while it is open): set by the gains wave
     int stamp;
-    int abort_code;         // != 0: the tick watchdog fired (a protocol bug, never a data condition): the kernel reports and leaves
     double node_cost[64];   // the node costs (the multi-kernel path parks them in the nodes' gap slots)
     long long t_phase;      // telemetry: cycle count at the start of the phase, and the recursion wave's split of it
     long long tele[4];      // [start -> first node, first node -> last node done, last node done -> the role returns, line search inside the role]
@@ -1767,7 +1766,7 @@ __global__ __launch_bounds__(256) void ik_fused_kernel(const IkBatchArgs a, cons
         for (int i = threadIdx.x; i < (int)(sizeof(RobotModelDev) / sizeof(int)); i += 256) dst[i] = src[i];
     }
     if (threadIdx.x < 64) s.ctl.ready[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { s.ctl.state_ready = 0; s.ctl.hand_count = 0; s.ctl.done_tick = 0x7fffffff; s.ctl.stamp = 0; s.ctl.abort_code = 0; s.args = a;
+    if (threadIdx.x == 0) { s.ctl.state_ready = 0; s.ctl.hand_count = 0; s.ctl.done_tick = 0x7fffffff; s.ctl.stamp = 0; s.args = a;
                             for (int k = 0; k < 4; ++k) { s.ctl.tele[k] = 0; s.ctl.wait[k] = 0; } }
     __syncthreads();
     const int limit = 24 * (a.T + 8);      // a pass takes T + ~6 ticks; the regularisation can restart it 18 times (1e-9 ... 1e9)
