@@ -25,14 +25,20 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # per-file extra flags (none now: -freciprocal-math -fapprox-func on ik_ddp.hip turns its 284 IEEE fp64 divisions into v_rcp_f64 +
 # Newton steps, measured gain on the MI355X: none -- the divisions sit off the chains that set the pace -- so IEEE division stays)
-FILE_FLAGS = {}
+# ik_ddp.hip: -ffp-contract=on.  hipcc's default for device code (fast) fuses a multiply into an add across statements, in the
+# back end, where the decision depends on what surrounds the expression -- and the same source, instantiated once per wave role
+# and per mapping, then rounds differently here and there (seen: one problem of 4096 whose final cost differed by one ulp between
+# the four-problems-per-wave line search and the role-split one).  With `on` a product is fused only with the sum of its own
+# expression, decided in the front end: every instantiation of a piece of source gets the same arithmetic, so "a problem's
+# result does not depend on how it was scheduled" holds by construction.
+FILE_FLAGS = {"ik_ddp.hip": ["-ffp-contract=on"]}
 
 
 def is_stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS + [os.path.abspath(__file__)]      # (this file: the flags live here)
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -506,3 +506,29 @@ def test_fused_kernel_restarts_its_riccati_pass(model):
     n = on["ik_iters"]
     for i in np.where(took)[0]:
         assert np.array_equal(on["ik_trace"][i, :n[i]], off["ik_trace"][i, :n[i]]), i
+
+
+def test_mappings_agree_bit_for_bit_at_full_size(model):
+    """4096 problems through every scheduling of the DDP -- line search always four problems per wave, always four step lengths
+    per problem, the default thresholds, and the default with the express lane -- must give the same bits in every output,
+    the reported cost included.  (With hipcc's default -ffp-contract=fast they did not quite: the back end fused multiplies into
+    adds of neighbouring statements differently in the different instantiations of the same source, and 3-14 problems of 4096
+    came out with a final cost one ulp apart; ik_ddp.hip is compiled with -ffp-contract=on, bunmpc_amd/build.py.)"""
+    from bunmpc_amd import _lib
+    from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
+    lib = _lib.lib()
+    wb = problems.make_wb_batch(model, 4096, seed=4196)
+    out = {}
+    for name, below, cap in (("default", 1024, -1), ("never_spec", 0, -1), ("always_spec", 1 << 30, -1), ("express", 1024, 96)):
+        old = lib.bmpc_ik_set_speculative_below(below)
+        try:
+            kb = KinoDynDeviceBatch(wb, model, num_iters=10, schedule={"express_cap": cap})
+            kb.solve()
+            out[name] = kb.results()
+        finally:
+            lib.bmpc_ik_set_speculative_below(old)
+    assert (out["express"]["ik_fused_iters"] > 0).sum() == 96
+    for name in ("never_spec", "always_spec", "express"):
+        for k in ("xs", "us", "ik_cost", "ik_stop", "ik_iters", "ik_status"):
+            d = np.where(np.any((out["default"][k] != out[name][k]).reshape(4096, -1), axis=1))[0]
+            assert len(d) == 0, (name, k, d[:8].tolist())
