@@ -14,7 +14,7 @@ import csv, glob, collections
 f = glob.glob("${out}_$tag/*/*counter_collection.csv")[0]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
-    for k in ("ik_state", "ik_calcdiff", "ik_backward", "ik_forward"):
+    for k in ("ik_state", "ik_calcdiff1", "ik_calcdiff_", "ik_backward", "ik_forward", "ik_fused"):
         if k in r["Kernel_Name"]:
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
