@@ -519,16 +519,32 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a
 // holds, and its second wave holds one through the walk only to wait at the barrier; a single wave spends 37 % fewer
 // wave-cycles per pair (the pair's latency, which is what counts when few problems are left, is 25 % longer).
 // Two such waves share a workgroup (and its copy of the robot model), each with a node pair of its own: 36.7 KB of LDS per
-// workgroup, four workgroups = eight waves per CU, which is what the registers allow.
-struct alignas(16) Calc1Lds { CalcNode nd[2][kCalcNodes]; RobotModelDev m; };
+// workgroup, four workgroups = eight waves per CU, which is what the registers allow.  The assembly of a node is a NON-INLINED
+// function (as the fused kernel's roles, further down): in one body with the walk, hipcc spilled 52 registers at the kernel's
+// 256 (122 under -ffp-contract=on); on its own the assembly has its own allocation, and at its call the walk's state is dead.
+struct alignas(16) Calc1Lds { CalcNode nd[2][kCalcNodes]; RobotModelDev m; IkBatchArgs args; };
+__shared__ Calc1Lds g_calc1;
+__device__ __forceinline__ IkBatchArgs uniform_args(const IkBatchArgs &g);      // every field through v_readfirstlane (defined with the fused kernel)
+__device__ __forceinline__ int uni(int v);
+__device__ __forceinline__ long uni(long v);
+__device__ __noinline__ void calc1_assemble(long b_, int t_, int h_) {
+    const IkBatchArgs a = uniform_args(g_calc1.args);
+    const long b = uni(b_);
+    const int t = uni(t_), h = uni(h_), lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6));
+    const IkLayout L = IkLayout::make(a.T);
+    double *ws = a.ws + b * L.total;
+    calc_assemble(a, b, t, g_calc1.nd[wave][h], ws, L, lane, batch_ptr(a.state_w, a.s_state_w, b), batch_ptr(a.ctrl_w, a.s_ctrl_w, b),
+                  ws + L.fs + (long)t * kNDX);
+}
 __global__ __launch_bounds__(128, 2) void ik_calcdiff1_kernel(const IkBatchArgs a) {
-    __shared__ Calc1Lds s;
+    Calc1Lds &s = g_calc1;
     const int nn = a.T + 1, groups = (nn + kCalcNodes - 1) / kCalcNodes;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     {
         const int *src = reinterpret_cast<const int *>(a.model);
         int *dst = reinterpret_cast<int *>(&s.m);
         for (int i = threadIdx.x; i < (int)(sizeof(RobotModelDev) / sizeof(int)); i += 128) dst[i] = src[i];
+        if (threadIdx.x == 0) s.args = a;
     }
     __syncthreads();        // (the only workgroup barrier: from here on the two waves have nothing to do with each other)
     const long unit = (long)blockIdx.x * 2 + wave;
@@ -540,7 +556,6 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff1_kernel(const IkBatchArgs 
     if (ws[L.scal + S_DONE] != 0.0 || ws[L.scal + S_RECALC] == 0.0) return;
     const RobotModelDev &m = s.m;
     CalcNode (&nd)[kCalcNodes] = s.nd[wave];
-    const double *state_w0 = batch_ptr(a.state_w, a.s_state_w, b), *ctrl_w0 = batch_ptr(a.ctrl_w, a.s_ctrl_w, b);
     UNROLL_RBD for (int h = 0; h < kCalcNodes; ++h) {
         const int t = t0 + h;
         if (t < nn) {
@@ -553,16 +568,18 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff1_kernel(const IkBatchArgs 
     const int hs = lane >> 5, hl = lane & 31, tw = t0 + hs;
     const bool wvalid = tw < nn;
     CalcNode &qw = nd[hs];
-    NodeTasks tkw{a.tasks + (b * nn + (wvalid ? tw : t0)) * kNodeTaskDoubles};
-    PartWalk pw;
-    double Rb[9], pb[3], Vb[6];
-    if (wvalid && hl < kNV) calc_walk(m, qw, tkw, hl, Rb, pb, Vb, pw);
-    if (wvalid) calc_fetch_state(qw, ws, L, tw, hl);
+    {
+        NodeTasks tkw{a.tasks + (b * nn + (wvalid ? tw : t0)) * kNodeTaskDoubles};
+        PartWalk pw;
+        double Rb[9], pb[3], Vb[6];
+        if (wvalid && hl < kNV) calc_walk(m, qw, tkw, hl, Rb, pb, Vb, pw);
+        if (wvalid) calc_fetch_state(qw, ws, L, tw, hl);
+        wave_sync();
+        if (wvalid && hl < kNV) calc_columns(m, qw, tkw, hl, pw);
+    }
     wave_sync();
-    if (wvalid && hl < kNV) calc_columns(m, qw, tkw, hl, pw);
-    wave_sync();
-    calc_assemble(a, b, t0, nd[0], ws, L, lane, state_w0, ctrl_w0, ws + L.fs + (long)t0 * kNDX);
-    if (t0 + 1 < nn) calc_assemble(a, b, t0 + 1, nd[1], ws, L, lane, state_w0, ctrl_w0, ws + L.fs + (long)(t0 + 1) * kNDX);
+    calc1_assemble(b, t0, 0);
+    if (t0 + 1 < nn) calc1_assemble(b, t0 + 1, 1);
 }
 
 // --------------------------------------------------------------------------- backward ---
