@@ -17,8 +17,8 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
-SOURCES = ["biconvex_admm.hip", "biconvex_latency.hip", "bunmpc_capi.hip", "ik_ddp.hip", "bunmpc_ik_capi.hip", "plan_gen.hip", "id_ctrl.hip", "perturb.hip"]
-HEADERS = [os.path.join(CSRC, h) for h in ("biconvex_kernels.h", "biconvex_lanes.h", "ik_types.h", "rbd_device.h", "rbd_quad.h", "lds_batch.h", "id_types.h", "perturb_types.h")] + \
+SOURCES = ["biconvex_admm.hip", "biconvex_admm_f32.hip", "biconvex_latency.hip", "bunmpc_capi.hip", "ik_ddp.hip", "bunmpc_ik_capi.hip", "plan_gen.hip", "id_ctrl.hip", "perturb.hip"]
+HEADERS = [os.path.join(CSRC, h) for h in ("biconvex_kernels.h", "biconvex_lanes.h", "biconvex_admm_body.h", "ik_types.h", "rbd_device.h", "rbd_quad.h", "lds_batch.h", "id_types.h", "perturb_types.h")] + \
           [os.path.join(os.path.dirname(_HERE), "include", "bunmpc.h")]
 LIB = os.path.join(_HERE, "libbunmpc_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -31,7 +31,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # the four-problems-per-wave line search and the role-split one).  With `on` a product is fused only with the sum of its own
 # expression, decided in the front end: every instantiation of a piece of source gets the same arithmetic, so "a problem's
 # result does not depend on how it was scheduled" holds by construction.
-FILE_FLAGS = {"ik_ddp.hip": ["-ffp-contract=on"]}
+# biconvex_admm_f32.hip: no SLP vectoriser -- packed fp32 operations cost this kernel ~90 registers and its two-waves-per-SIMD
+# build 40-60 values in scratch memory (the reasons and the measurement are in the file's header).
+FILE_FLAGS = {"ik_ddp.hip": ["-ffp-contract=on"], "biconvex_admm_f32.hip": ["-fno-slp-vectorize"]}
 
 
 def is_stale():

@@ -1,0 +1,487 @@
+// The body of the batched centroidal ADMM kernel (one knot per lane): template admm_body<R, LPP, E, RAW, HASQF>.  Included inside
+// the anonymous namespace of biconvex_admm.hip (fp64 instantiations) and of biconvex_admm_f32.hip (fp32 instantiations, built
+// with other compiler flags: see bunmpc_amd/build.py); the mapping, the reference lines and the algebra are described at the
+// top of biconvex_admm.hip.
+#pragma once
+
+// ------------------------------------------------------------------------------
+// Per-iteration algebra (what differs from the reference's formulation, all of it exact
+// algebra on the same quadratic):
+//   * acceptance test.  fista.cpp:16 tests  f(y+) - f(y) > g.d + (L/2)|d|^2 ; for the quadratic
+//     f = y'Qy + q'y + rho|Ay - b + P|^2 that difference is  g.d + d'Qd + rho|A d|^2  identically,
+//     and A d = (A y+ + bPk) - (A y + bPk) is at hand, so the test becomes
+//     d'Qd + rho|A d|^2 > (L/2)|d|^2 : two segment sums instead of three, no cancellation.
+//   * x_init rows.  A_f's last nine rows are the identity on X_0 (centroidal.hpp:22-27), i.e. the
+//     term rho|X_0 - x_init + P_H|^2: a diagonal quadratic in X_0.  Lane 0 adds rho to its Q and
+//     2 rho (P_H - x_init) to its q instead of every lane carrying nine extra residual rows.
+//   * momentum coefficients (t_k - 1)/t_{k+1} (fista.cpp:34-35) depend on the iteration index
+//     only; each wave tabulates them once in LDS.
+//   * a problem that finishes (|d| < tol or maxit) has its iterate latched into `fin` registers
+//     at that moment; the loop body itself carries no per-lane freeze selects.
+template <typename R, int LPP, int E, bool RAW, bool HASQF>
+__device__ __forceinline__ void admm_body(const BatchArgs &a) {
+    extern __shared__ double lds_raw[];
+    R *cmtab = reinterpret_cast<R *>(lds_raw);   // [maxit]
+    constexpr int NF = 3 * E;           // force variables per knot
+    constexpr int NB = RAW ? 9 : 3;     // bounded components per knot
+    const int lane = threadIdx.x & 63;
+    const int t = lane % LPP;           // knot owned by this lane
+    const int seg = lane / LPP;
+    const int H = a.H;
+    const long prob = (long)blockIdx.x * (64 / LPP) + seg;
+    const bool pvalid = prob < a.B;
+    const bool kvalid = pvalid && t <= H;  // owns knot t (X block t)
+    const bool rvalid = pvalid && t < H;   // owns dynamics row-block t and force block t
+    const bool l0 = pvalid && t == 0;      // also owns the x_init rows 9H..9H+8
+    const long nx = 9L * (H + 1), nf = (long)NF * H;
+    const long pb = pvalid ? prob : 0;
+    const mask_t rvalid_m = __ballot(rvalid), kvalid_m = __ballot(kvalid);
+
+    const R m = (R)a.c.m, rho = (R)a.c.rho, mu = (R)a.c.mu, beta = (R)a.c.beta;
+    const double tol = a.c.tol, exit_tol = a.c.exit_tol;   // exit tests are evaluated in fp64 whatever R is
+    const int maxit = a.c.maxit;
+    const R rho2 = R(2) * rho;
+
+    // Iterates at phase boundaries (X, F, P of this segment's problem) live in LDS, each lane touching
+    // only its own knot's blocks (lane 0 also the x_init rows of P): HBM sees the inputs once and the
+    // results once.  Layout after the momentum table: per segment [X nx | P nx | F nf].
+    R *seg_lds = cmtab + ((maxit + 1) & ~1) + (long)seg * (2 * nx + nf);
+    R *Xg = seg_lds + 9L * t;
+    R *Pg = seg_lds + nx + 9L * t;
+    R *PIg = seg_lds + nx + 9L * H;
+    R *Fg = seg_lds + 2 * nx + (long)NF * t;
+    // Global arrays are addressed as a WAVE-UNIFORM base (the block of the wave's first problem: scalar registers) plus a 32-bit
+    // per-lane byte offset (problem within the wave, knot): `global_load v, v_off, s[base]`.  A 64-bit pointer per lane and array
+    // -- what `a.X + pb * nx + 9 * t` makes -- held some thirty vector registers over both FISTA loops, and they were what the
+    // fp32 build (256 registers, two waves per SIMD) parked in scratch memory.  Every lane's offset is that of an EXISTING
+    // element (lanes past the horizon take the last knot's, lanes of a padding problem the wave's first problem): the loads
+    // are unconditional -- straight-line code in which base + offset folds into the instruction, instead of some sixty
+    // exec-masked blocks each needing the address as a 64-bit register pair -- and what a lane has no business with is
+    // replaced by zero after the load (ldz).  Stores stay conditional.
+    const long wave0 = (long)blockIdx.x * (64 / LPP);
+    const unsigned sl = pvalid ? (unsigned)seg : 0u;
+    const unsigned tk = (unsigned)(t <= H ? t : H), tr = (unsigned)(t < H ? t : H - 1);
+    const unsigned oX = 8u * (sl * (unsigned)nx + 9u * tk);                  // X, P, Qx, qx, lbx, ubx: [B][9 (H + 1)]
+    const unsigned oPI = 8u * (sl * (unsigned)nx + 9u * (unsigned)H);
+    const unsigned oF = 8u * (sl * (unsigned)nf + (unsigned)NF * tr);        // F, Qf, qf: [B][3 E H]
+    const unsigned oK = 8u * (sl * (unsigned)H + tr);                        // dt: [B][H]; cnt_plan: E * 4 doubles per entry
+    const unsigned oP9 = 8u * 9u * sl;                                        // x_init, X_ter: [B][9]
+    double *const Xu = a.X + wave0 * nx, *const Fu = a.F + wave0 * nf, *const Pu = a.P + wave0 * nx;
+    const double *const xinit_u = a.x_init + wave0 * 9;
+
+    {   // momentum table: t+ = 1 + sqrt(1 + 4 t^2)/2 (sic, fista.cpp:34), c = (t - 1)/t+
+        double tk = 1.0;
+        for (int i = 0; i < maxit; ++i) {
+            const double tk1 = 1.0 + sqrt(1.0 + 4.0 * tk * tk) * 0.5;
+            if (lane == 0) cmtab[i] = (R)((tk - 1.0) / tk1);
+            tk = tk1;
+        }
+        __syncthreads();
+    }
+
+    const R dt = ldz<R>(a.dt + wave0 * H, oK, 0, rvalid);
+    const R dtp = from_prev(dt);  // dt of knot t-1 (0 for t == 0: previous lane is a dead/terminal lane)
+    const bool cold = a.cold_start != 0;      // 1: fresh solver object (iterates and step constants reset); 2: iterates only --
+    const bool fresh_L = a.cold_start == 1;   // FISTA's L_ is set in the constructor and survives every optimize call (fista.hpp:52)
+    R L_x = (R)(fresh_L ? a.L0_x : *at(a.L_x + wave0, 8u * sl));
+    R L_f = (R)(fresh_L ? a.L0_f : *at(a.L_f + wave0, 8u * sl));
+    if (cold) {  // KinoDynMP::set_warm_starts (kino_dyn.cpp:83-99): X = tile(x_init), F = 0, P = 0
+        if (kvalid) { UNROLL for (int l = 0; l < 9; ++l) Xg[l] = (R)at(xinit_u, oP9)[l]; }
+        if (rvalid) {
+            UNROLL for (int j = 0; j < NF; ++j) Fg[j] = R(0);
+            UNROLL for (int l = 0; l < 9; ++l) Pg[l] = R(0);
+        }
+        if (l0) { UNROLL for (int l = 0; l < 9; ++l) PIg[l] = R(0); }
+    } else {     // set_warm_start_vars: bring the caller's iterates on chip
+        if (kvalid) { UNROLL for (int l = 0; l < 9; ++l) Xg[l] = (R)at(Xu, oX)[l]; }
+        if (rvalid) {
+            UNROLL for (int j = 0; j < NF; ++j) Fg[j] = (R)at(Fu, oF)[j];
+            UNROLL for (int l = 0; l < 9; ++l) Pg[l] = (R)at(Pu, oX)[l];
+        }
+        if (l0) { UNROLL for (int l = 0; l < 9; ++l) PIg[l] = (R)at(Pu, oPI)[l]; }
+    }
+    mask_t alive = __ballot(pvalid);
+    int n_admm = 0, it_f = 0, it_x = 0, bt_f = 0, bt_x = 0, status = 0;
+    double last_viol = 0.0;
+
+    for (int it = 0; it < a.c.num_iters; ++it) {
+        if (alive == 0) break;
+        // contact data of this knot: flags c_n, positions r_n  (centroidal.cpp:39-49); re-read in
+        // each phase (L2-resident) rather than held in registers across the FISTA loops
+        const double *const cnt_u = a.cnt_plan + wave0 * H * (E * 4);
+        const unsigned oC = oK * (unsigned)(E * 4);
+
+        // =================================================================== F step
+        {
+            const unsigned ph = opaque_zero();      // see opaque_zero (biconvex_lanes.h): the inputs are re-read in each phase
+            R c[E], r[E][3];
+            UNROLL for (int n = 0; n < E; ++n) {
+                c[n] = ldz<R>(cnt_u, oC + ph, 4 * n, rvalid);
+                UNROLL for (int k = 0; k < 3; ++k) r[n][k] = ldz<R>(cnt_u, oC + ph, 4 * n + 1 + k, rvalid);
+            }
+            R X[9];
+            UNROLL for (int l = 0; l < 9; ++l) X[l] = kvalid ? Xg[l] : R(0);
+            // bPk rows 9t+3..8 = -b_x + P, b_x = X_{t+1} - X_t (+g dt)   (centroidal.cpp:60-65)
+            R bpk[6];
+            UNROLL for (int k = 0; k < 6; ++k) {
+                const R xn = from_next(X[3 + k]);
+                R bx = xn - X[3 + k];
+                if (k == 2) bx += R(kGravity) * dt;
+                bpk[k] = rvalid ? (-bx + Pg[3 + k]) : R(0);
+            }
+            // A_x entries of this knot (centroidal.cpp:67-81)
+            R an[E], sp[E][3];
+            UNROLL for (int n = 0; n < E; ++n) {
+                an[n] = c[n] * (dt / m);
+                UNROLL for (int k = 0; k < 3; ++k) sp[n][k] = c[n] * (X[k] - r[n][k]) * dt;
+            }
+            // The gradient is carried as HALF of itself, gh = Q y + q/2 + rho A^T(A y + bPk), and the step as y - (2/L) gh:
+            // scaling by two is exact in binary floating point, so every iterate has the bits of the reference's
+            // y - g/L, and the doubled copies of the weights (2 Q, 2 rho) need no registers.
+            R wf[NF], qf[HASQF ? NF : 1];
+            UNROLL for (int j = 0; j < NF; ++j) {
+                wf[j] = RAW ? ldz<R>(a.Qf + wave0 * nf, oF + ph, j, rvalid)
+                            : ldz<R>(a.W_F + wave0 * a.sW_F, 8u * (sl * (unsigned)a.sW_F + (unsigned)NF * tr) + ph, j, rvalid);
+                if (HASQF) qf[j] = R(0.5) * ldz<R>(a.qf + wave0 * nf, oF + ph, j, rvalid);
+            }
+            // u = A v + bPk on rows 9t+3..8
+            auto applyA = [&](const R (&v)[NF], R (&u)[6]) {
+                R s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
+                UNROLL for (int n = 0; n < E; ++n) {
+                    const R vx = v[3 * n], vy = v[3 * n + 1], vz = v[3 * n + 2];
+                    s0 += an[n] * vx; s1 += an[n] * vy; s2 += an[n] * vz;
+                    s3 += sp[n][2] * vy - sp[n][1] * vz;
+                    s4 += sp[n][0] * vz - sp[n][2] * vx;
+                    s5 += sp[n][1] * vx - sp[n][0] * vy;
+                }
+                u[0] = s0 + bpk[0]; u[1] = s1 + bpk[1]; u[2] = s2 + bpk[2];
+                u[3] = s3 + bpk[3]; u[4] = s4 + bpk[4]; u[5] = s5 + bpk[5];
+            };
+
+            // FISTA state.  x lives in two buffers (xa/xb, A-images ra/rb) whose roles swap every
+            // iteration, so "x_k = x_k_1" (fista.cpp:37) costs no register moves.
+            R xa[NF], xb[NF], y[NF], ra[6], rb[6], ry[6];
+            UNROLL for (int j = 0; j < NF; ++j) { xa[j] = rvalid ? Fg[j] : R(0); y[j] = xa[j]; }
+            applyA(y, ry);
+            UNROLL for (int k = 0; k < 6; ++k) ra[k] = ry[k];
+            const R mu2 = mu * mu, imu = R(1) / (mu * mu + R(1));
+            const double tol2 = tol * tol;
+            R invL = R(2) * (R(1) / L_f);      // 2 / L, see above
+            mask_t act = alive;
+            // one FISTA iteration: reads x from xo/ro, leaves x_{k+1} in xn/rn, advances y/ry
+            auto iterate = [&](const R (&xo)[NF], const R (&ro)[6], R (&xn)[NF], R (&rn)[6], int i) {
+                const R cm = cmtab[i];
+                mask_t done;
+                mask_t pend = act;
+                for (;;) {  // backtracking (fista.cpp:8-26); segments that accepted recompute the same values
+                    // g/2 = Q y + q/2 + rho A^T (A y + bPk)          (problem.cpp:36-38,54-56), the step y - (2/L) g/2 and the
+                    // "SoC" projection exactly as fista.cpp:52-70 writes it (zeroing by a 0 / 1 factor: one select per foot)
+                    unsigned long long anycone = 0;     // lanes with a force on the cone branch, as a scalar mask
+                    R fr[NF];
+                    UNROLL for (int n = 0; n < E; ++n) {
+                        const R zx = an[n] * ry[0] - sp[n][2] * ry[4] + sp[n][1] * ry[5];
+                        const R zy = an[n] * ry[1] + sp[n][2] * ry[3] - sp[n][0] * ry[5];
+                        const R zz = an[n] * ry[2] - sp[n][1] * ry[3] + sp[n][0] * ry[4];
+                        R gx = fmaR(wf[3 * n], y[3 * n], rho * zx), gy = fmaR(wf[3 * n + 1], y[3 * n + 1], rho * zy),
+                          gz = fmaR(wf[3 * n + 2], y[3 * n + 2], rho * zz);
+                        if (HASQF) { gx += qf[3 * n]; gy += qf[3 * n + 1]; gz += qf[3 * n + 2]; }
+                        fr[3 * n] = fmaR(-gx, invL, y[3 * n]);
+                        fr[3 * n + 1] = fmaR(-gy, invL, y[3 * n + 1]);
+                        fr[3 * n + 2] = fmaR(-gz, invL, y[3 * n + 2]);
+                        const R s = fmaR(fr[3 * n], fr[3 * n], fr[3 * n + 1] * fr[3 * n + 1]);
+                        const R fz = fr[3 * n + 2];
+                        const bool zero = (s * mu < -fz) || (fz < 0);
+                        anycone |= __ballot(!zero && (s > mu * fz));
+                        const R keep = zero ? R(0) : R(1);
+                        xn[3 * n] = keep * fr[3 * n];
+                        xn[3 * n + 1] = keep * fr[3 * n + 1];
+                        xn[3 * n + 2] = keep * fz;
+                    }
+                    if (anycone != 0) {   // cone branch (fista.cpp:64-68); skipped while no lane needs it
+                        UNROLL for (int n = 0; n < E; ++n) {
+                            const R s = fmaR(fr[3 * n], fr[3 * n], fr[3 * n + 1] * fr[3 * n + 1]);
+                            const R fz = fr[3 * n + 2];
+                            const bool zero = (s * mu < -fz) || (fz < 0);
+                            const bool cone = !zero && (s > mu * fz);
+                            const R k = fast_div(fmaR(mu2, s, mu * fz), (mu2 + R(1)) * s);
+                            xn[3 * n] = cone ? fr[3 * n] * k : xn[3 * n];
+                            xn[3 * n + 1] = cone ? fr[3 * n + 1] * k : xn[3 * n + 1];
+                            xn[3 * n + 2] = cone ? fmaR(mu, s, fz) * imu : xn[3 * n + 2];
+                        }
+                    }
+                    applyA(xn, rn);
+                    R g2 = 0, cv = 0, e2 = 0, dv[NF];
+                    UNROLL for (int j = 0; j < NF; ++j) {
+                        const R d = xn[j] - y[j];
+                        dv[j] = d;
+                        g2 = fmaR(d, d, g2);
+                        cv = fmaR(wf[j] * d, d, cv);
+                    }
+                    if (sizeof(R) == sizeof(double)) {
+                        UNROLL for (int k = 0; k < 6; ++k) { const R e = rn[k] - ry[k]; e2 = fmaR(e, e, e2); }
+                    } else {
+                        // fp32: A d = (A y+ + bPk) - (A y + bPk) by subtraction carries the rounding of the two images (1e-7 of
+                        // |A y|, whatever |d| is); near convergence rho |noise|^2 then exceeds (L/2)|d|^2 and the test retries
+                        // for ever (L_f x 1.5 until it overflows: seen on ~1.5 % of the trot problems).  A applied to d itself
+                        // has the rounding of |A d|.
+                        R s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
+                        UNROLL for (int n = 0; n < E; ++n) {
+                            const R vx = dv[3 * n], vy = dv[3 * n + 1], vz = dv[3 * n + 2];
+                            s0 += an[n] * vx; s1 += an[n] * vy; s2 += an[n] * vz;
+                            s3 += sp[n][2] * vy - sp[n][1] * vz;
+                            s4 += sp[n][0] * vz - sp[n][2] * vx;
+                            s5 += sp[n][1] * vx - sp[n][0] * vy;
+                        }
+                        e2 = s0 * s0 + s1 * s1 + s2 * s2 + s3 * s3 + s4 * s4 + s5 * s5;
+                    }
+                    cv = fmaR(rho, e2, cv);
+                    double g2s = (double)g2, cvs = (double)cv;
+                    seg_sum2<LPP>(g2s, cvs);
+                    // fista.cpp:14-17: G = sqrt(g2); retry if cv > (L/2) G*G; done if G < tol.  G*G and g2
+                    // differ by a few ulp, so outside a 1e-14 relative band the sqrt cannot change either
+                    // decision; inside it the reference expression is evaluated as written.
+                    const double Lh = (double)L_f * 0.5, rhs = Lh * g2s;
+                    mask_t bt = __ballot(cvs > rhs);
+                    done = __ballot(g2s < tol2);
+                    const mask_t edge = __ballot((fabs(cvs - rhs) <= 1e-14 * rhs) || (fabs(g2s - tol2) <= 1e-14 * tol2));
+                    if (edge != 0) {
+                        const double Gn = sqrt(g2s);
+                        bt = __ballot(cvs > Lh * (Gn * Gn));
+                        done = __ballot(Gn < tol);
+                    }
+                    bt &= pend;
+                    pend = bt;
+                    if (bt == 0) break;
+                    if (lanes(bt)) { L_f *= beta; ++bt_f; }
+                    invL = R(2) * (R(1) / L_f);
+                }
+                const mask_t last = act & (i == maxit - 1 ? ~mask_t(0) : done) & rvalid_m;
+                if (lanes(last)) { UNROLL for (int j = 0; j < NF; ++j) Fg[j] = xn[j]; }   // x_k of a finishing problem is latched
+                // momentum (fista.cpp:33-47); A-images follow by linearity
+                UNROLL for (int j = 0; j < NF; ++j) y[j] = fmaR(cm, xn[j] - xo[j], xn[j]);
+                UNROLL for (int k = 0; k < 6; ++k) ry[k] = fmaR(cm, rn[k] - ro[k], rn[k]);
+                it_f += lanes(act) ? 1 : 0;
+                act &= ~done;
+            };
+            for (int i = 0; i < maxit; i += 2) {
+                if (act == 0) break;
+                iterate(xa, ra, xb, rb, i);
+                if (i + 1 >= maxit || act == 0) break;
+                iterate(xb, rb, xa, ra, i + 1);
+            }
+        }
+
+        // =================================================================== X step
+        {
+            const unsigned ph = opaque_zero();
+            R c[E], r[E][3];
+            UNROLL for (int n = 0; n < E; ++n) {
+                c[n] = ldz<R>(cnt_u, oC + ph, 4 * n, rvalid);
+                UNROLL for (int k = 0; k < 3; ++k) r[n][k] = ldz<R>(cnt_u, oC + ph, 4 * n + 1 + k, rvalid);
+            }
+            // A_f / b_f entries of this knot from the new forces (centroidal.cpp:86-127)
+            R SX = 0, SY = 0, SZ = 0, bf[9];
+            {
+                R b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0, b8 = 0;
+                UNROLL for (int n = 0; n < E; ++n) {
+                    const R fx = rvalid ? Fg[3 * n] : R(0), fy = rvalid ? Fg[3 * n + 1] : R(0),
+                            fz = rvalid ? Fg[3 * n + 2] : R(0);
+                    SX += c[n] * fx * dt; SY += c[n] * fy * dt; SZ += c[n] * fz * dt;
+                    b3 += -c[n] * fx * dt / m; b4 += -c[n] * fy * dt / m; b5 += -c[n] * fz * dt / m;
+                    b6 += (c[n] * fy * r[n][2] - c[n] * fz * r[n][1]) * dt;
+                    b7 += (c[n] * fz * r[n][0] - c[n] * fx * r[n][2]) * dt;
+                    b8 += (c[n] * fx * r[n][1] - c[n] * fy * r[n][0]) * dt;
+                }
+                bf[0] = 0; bf[1] = 0; bf[2] = 0;
+                bf[3] = b3; bf[4] = b4; bf[5] = b5 + R(kGravity) * dt;
+                bf[6] = b6; bf[7] = b7; bf[8] = b8;
+            }
+            R bpk[9];
+            UNROLL for (int l = 0; l < 9; ++l) bpk[l] = rvalid ? (-bf[l] + Pg[l]) : R(0);
+            // cost and bounds of this knot
+            R qd[9], q[9], lb[NB], ub[NB];
+            if (RAW) {
+                UNROLL for (int l = 0; l < 9; ++l) {
+                    qd[l] = ldz<R>(a.Qx + wave0 * nx, oX + ph, l, kvalid);
+                    q[l] = R(0.5) * ldz<R>(a.qx + wave0 * nx, oX + ph, l, kvalid);     // q/2
+                }
+                UNROLL for (int l = 0; l < NB; ++l) {
+                    const R lo = (R)at(a.lbx + wave0 * nx, oX + ph)[l], hi = (R)at(a.ubx + wave0 * nx, oX + ph)[l];
+                    lb[l] = kvalid ? lo : R(-INFINITY);
+                    ub[l] = kvalid ? hi : R(INFINITY);
+                }
+            } else {
+                // create_cost_X (biconvex.cpp:57-72)
+                UNROLL for (int l = 0; l < 9; ++l) {
+                    const double w_run = at(a.W_X + wave0 * a.sW_X, 8u * (sl * (unsigned)a.sW_X + 9u * tr) + ph)[l];
+                    const double w_ter = at(a.W_X_ter + wave0 * a.sW_X_ter, 8u * sl * (unsigned)a.sW_X_ter + ph)[l];
+                    const double x_run = at(a.X_nom + wave0 * 9L * H, 8u * 9u * (sl * (unsigned)H + tr) + ph)[l];
+                    const double x_ter = at(a.X_ter + wave0 * 9, oP9 + ph)[l];
+                    const R w = (R)(rvalid ? w_run : (kvalid ? w_ter : 0.0));
+                    const R xr = (R)(rvalid ? x_run : (kvalid ? x_ter : 0.0));
+                    qd[l] = w;
+                    q[l] = -(xr * w);              // q/2 (create_cost_X: q = -2 W x_ref)
+                }
+                // create_bound_constraints (biconvex.cpp:27-55): CoM box around the feet
+                R csum = 0;
+                UNROLL for (int n = 0; n < E; ++n) csum += c[n];
+                const bool bounded = rvalid && csum > 0;
+                UNROLL for (int k = 0; k < 3; ++k) {
+                    R mx = r[0][k], mn = r[0][k];
+                    UNROLL for (int n = 1; n < E; ++n) { mx = fmaxR(mx, r[n][k]); mn = fminR(mn, r[n][k]); }
+                    const double *bnd = at(a.bounds + wave0 * a.sbounds, 8u * (sl * (unsigned)a.sbounds + 6u * tr) + ph);
+                    const double b_lo = bnd[k], b_hi = bnd[3 + k];
+                    const R blo = (R)(bounded ? b_lo : 0.0);
+                    const R bhi = (R)(bounded ? b_hi : 0.0);
+                    lb[k] = bounded ? mx + blo : R(-INFINITY);
+                    ub[k] = bounded ? mn + bhi : R(INFINITY);
+                }
+            }
+            // x_init rows folded into lane 0's diagonal cost:  rho |X_0 + (P_H - x_init)|^2   (q holds q/2: half-gradient form,
+            // see the force step)
+            UNROLL for (int l = 0; l < 9; ++l) {
+                const R xi = (R)at(xinit_u, oP9 + ph)[l];
+                const R bpi = l0 ? (PIg[l] - xi) : R(0);
+                qd[l] += l0 ? rho : R(0);
+                q[l] = fmaR(rho, bpi, q[l]);
+            }
+            UNROLL for (int l = 0; l < NB; ++l) {   // quieted once, so the clamp is a bare min/max pair
+                lb[l] = __builtin_canonicalize(lb[l]);
+                ub[l] = __builtin_canonicalize(ub[l]);
+            }
+            const int rmask = rvalid ? -1 : 0;      // row-block mask: lanes t >= H own no dynamics rows
+            // u = A_f v + bPk on row-block t; vn = v of knot t+1
+            auto applyA = [&](const R (&v)[9], R (&u)[9]) {
+                R vn[9];
+                UNROLL for (int l = 0; l < 9; ++l) vn[l] = from_next(v[l]);
+                R w[9];
+                UNROLL for (int l = 0; l < 9; ++l) w[l] = v[l] - vn[l];
+                UNROLL for (int k = 0; k < 3; ++k) w[k] += dt * vn[3 + k];
+                w[6] += SY * v[2] - SZ * v[1];
+                w[7] += SZ * v[0] - SX * v[2];
+                w[8] += SX * v[1] - SY * v[0];
+                UNROLL for (int l = 0; l < 9; ++l) u[l] = keep_if(w[l] + bpk[l], rmask);
+            };
+
+            R xa[9], xb[9], y[9], ra[9], rb[9], ry[9];
+            UNROLL for (int l = 0; l < 9; ++l) { xa[l] = kvalid ? Xg[l] : R(0); y[l] = xa[l]; }
+            applyA(y, ry);
+            UNROLL for (int l = 0; l < 9; ++l) ra[l] = ry[l];
+            const double tol2 = tol * tol;
+            R invL = R(2) * (R(1) / L_x);
+            mask_t act = alive;
+            auto iterate = [&](const R (&xo)[9], const R (&ro)[9], R (&xn)[9], R (&rn)[9], int i) {
+                const R cm = cmtab[i];
+                mask_t done;
+                mask_t pend = act;
+                for (;;) {
+                    {   // half gradient Q y + q/2 + rho A_f^T (A_f y + bPk), step, box projection (fista.cpp:10); inside the retry
+                        // loop like the force step's
+                        R z[9], wp[9];
+                        UNROLL for (int l = 0; l < 9; ++l) wp[l] = from_prev(ry[l]);  // row-block t-1 (0 for t == 0)
+                        UNROLL for (int l = 0; l < 9; ++l) z[l] = ry[l] - wp[l];
+                        UNROLL for (int k = 0; k < 3; ++k) z[3 + k] = fmaR(dtp, wp[k], z[3 + k]);
+                        z[0] += SZ * ry[7] - SY * ry[8];
+                        z[1] += SX * ry[8] - SZ * ry[6];
+                        z[2] += SY * ry[6] - SX * ry[7];
+                        UNROLL for (int l = 0; l < 9; ++l) {
+                            const R g = fmaR(qd[l], y[l], fmaR(rho, z[l], q[l]));
+                            R v = fmaR(-g, invL, y[l]);
+                            if (l < NB) v = fmaxR(fminR(v, ub[l]), lb[l]);
+                            xn[l] = v;
+                        }
+                    }
+                    applyA(xn, rn);
+                    R g2 = 0, cv = 0, e2 = 0;
+                    UNROLL for (int l = 0; l < 9; ++l) {
+                        const R d = xn[l] - y[l];
+                        const R e = rn[l] - ry[l];
+                        g2 = fmaR(d, d, g2);
+                        cv = fmaR(qd[l] * d, d, cv);
+                        e2 = fmaR(e, e, e2);
+                    }
+                    cv = fmaR(rho, e2, cv);
+                    double g2s = (double)g2, cvs = (double)cv;
+                    seg_sum2<LPP>(g2s, cvs);
+                    const double Lh = (double)L_x * 0.5, rhs = Lh * g2s;   // see the force loop for the sqrt-free form
+                    mask_t bt = __ballot(cvs > rhs);
+                    done = __ballot(g2s < tol2);
+                    const mask_t edge = __ballot((fabs(cvs - rhs) <= 1e-14 * rhs) || (fabs(g2s - tol2) <= 1e-14 * tol2));
+                    if (edge != 0) {
+                        const double Gn = sqrt(g2s);
+                        bt = __ballot(cvs > Lh * (Gn * Gn));
+                        done = __ballot(Gn < tol);
+                    }
+                    bt &= pend;
+                    pend = bt;
+                    if (bt == 0) break;
+                    if (lanes(bt)) { L_x *= beta; ++bt_x; }
+                    invL = R(2) * (R(1) / L_x);
+                }
+                const mask_t last = act & (i == maxit - 1 ? ~mask_t(0) : done) & kvalid_m;
+                if (lanes(last)) { UNROLL for (int l = 0; l < 9; ++l) Xg[l] = xn[l]; }
+                UNROLL for (int l = 0; l < 9; ++l) {
+                    y[l] = fmaR(cm, xn[l] - xo[l], xn[l]);
+                    ry[l] = fmaR(cm, rn[l] - ro[l], rn[l]);
+                }
+                it_x += lanes(act) ? 1 : 0;
+                act &= ~done;
+            };
+            for (int i = 0; i < maxit; i += 2) {
+                if (act == 0) break;
+                iterate(xa, ra, xb, rb, i);
+                if (i + 1 >= maxit || act == 0) break;
+                iterate(xb, rb, xa, ra, i + 1);
+            }
+            R fin[9];
+            UNROLL for (int l = 0; l < 9; ++l) fin[l] = kvalid ? Xg[l] : R(0);
+
+            // dyn_violation = A_f X - b_f ; P += dyn_violation          (biconvex.cpp:98-99)
+            double v2 = 0;   // the dynamics violation is accumulated in fp64 whatever R is
+            {
+                R xn[9], w[9];
+                UNROLL for (int l = 0; l < 9; ++l) xn[l] = from_next(fin[l]);
+                UNROLL for (int l = 0; l < 9; ++l) w[l] = fin[l] - xn[l];
+                UNROLL for (int k = 0; k < 3; ++k) w[k] += dt * xn[3 + k];
+                w[6] += SY * fin[2] - SZ * fin[1];
+                w[7] += SZ * fin[0] - SX * fin[2];
+                w[8] += SX * fin[1] - SY * fin[0];
+                const bool al = lanes(alive);
+                UNROLL for (int l = 0; l < 9; ++l) {
+                    const R d = rvalid ? (w[l] - bf[l]) : R(0);
+                    const R xi = (R)at(xinit_u, oP9 + ph)[l];
+                    const R di = l0 ? (fin[l] - xi) : R(0);
+                    if (al && rvalid) Pg[l] += d;
+                    if (al && l0) PIg[l] += di;
+                    v2 += (double)d * (double)d + (double)di * (double)di;
+                }
+            }
+            v2 = seg_sum<LPP>(v2);
+            const double nrm = sqrt(v2);
+            if (lanes(alive)) {
+                last_viol = nrm;
+                ++n_admm;
+                if (a.hist && l0) *at(a.hist + wave0 * a.c.num_iters, 8u * (sl * (unsigned)a.c.num_iters + (unsigned)it)) = nrm;
+                if (isnan(nrm)) status = 2;                                   // biconvex.cpp:106-109
+            }
+            alive &= ~__ballot(isnan(nrm) || nrm < exit_tol);                 // biconvex.cpp:106-109, 111-114
+        }
+    }
+
+    // ---- results: one pass from LDS to the output blocks
+    if (kvalid) { UNROLL for (int l = 0; l < 9; ++l) at(Xu, oX)[l] = (double)Xg[l]; }
+    if (rvalid) {
+        UNROLL for (int j = 0; j < NF; ++j) at(Fu, oF)[j] = (double)Fg[j];
+        UNROLL for (int l = 0; l < 9; ++l) at(Pu, oX)[l] = (double)Pg[l];
+    }
+    if (l0) { UNROLL for (int l = 0; l < 9; ++l) at(Pu, oPI)[l] = (double)PIg[l]; }
+    if (l0) {
+        *at(a.L_x + wave0, 8u * sl) = (double)L_x;
+        *at(a.L_f + wave0, 8u * sl) = (double)L_f;
+        if (a.dyn_viol) *at(a.dyn_viol + wave0, 8u * sl) = last_viol;
+        if (a.stats) {
+            int *s = a.stats + (wave0 + sl) * kStats;
+            s[0] = n_admm; s[1] = it_f; s[2] = it_x; s[3] = bt_f; s[4] = bt_x; s[5] = status;
+        }
+    }
+}

@@ -62,6 +62,10 @@ bool latency_mapping_fits(const BatchArgs &a, int n_eff);
 hipError_t launch_biconvex_latency(const BatchArgs &a, hipStream_t stream);
 int set_latency_mapping_max_batch(int max_batch);   // returns the old value
 
+// fp32 instantiations (biconvex_admm_f32.hip); called by launch_biconvex_admm with the lanes per problem (16 / 32 / 64), the grid
+// and the LDS bytes it has worked out
+hipError_t launch_biconvex_admm_f32(const BatchArgs &a, int lpp, unsigned grid, size_t lds, hipStream_t stream);
+
 // Lane-exchange self test (DPP shifts and segment sums used by the kernel).
 // out must hold 6*64 doubles.
 hipError_t launch_lane_selftest(const double *in, double *out, hipStream_t stream);

@@ -85,8 +85,24 @@ __device__ __forceinline__ void seg_sum2(double &a, double &b) {
     }
 }
 
+// element of a global array: wave-uniform base + 32-bit per-lane byte offset (global_load v, v_off, s[base:base+1])
+__device__ __forceinline__ const double *at(const double *ubase, unsigned byte_off) {
+    return reinterpret_cast<const double *>(reinterpret_cast<const char *>(ubase) + byte_off);
+}
+__device__ __forceinline__ double *at(double *ubase, unsigned byte_off) {
+    return reinterpret_cast<double *>(reinterpret_cast<char *>(ubase) + byte_off);
+}
+// A zero the optimiser cannot see through, added to the offsets of a phase's input loads: the inputs of a problem do not change
+// during a solve, so with plain offsets hipcc hoists the LOADED VALUES (weights, contact plan, bounds: ~60 registers) out of the
+// ADMM loop and carries them across both FISTA loops; re-reading them in each of the ten ADMM iterations (L2-resident) is free.
+__device__ __forceinline__ unsigned opaque_zero() { unsigned z = 0; asm volatile("" : "+v"(z)); return z; }
 // HBM holds fp64 whatever the arithmetic type R of the kernel; conversion happens at the load / store
-template <typename R> __device__ __forceinline__ R ldz(const double *p, long i, bool ok) { return ok ? (R)p[i] : R(0); }
+// (the constant element index stays outside the 32-bit offset: it folds into the instruction's immediate)
+// The load is UNCONDITIONAL (the caller's offset names an existing element in every lane); `ok` only decides what is kept.
+template <typename R> __device__ __forceinline__ R ldz(const double *ubase, unsigned byte_off, int idx, bool ok) {
+    const double v = at(ubase, byte_off)[idx];
+    return ok ? (R)v : R(0);
+}
 
 // v where m is all ones, +0.0 where m is 0 -- two v_and_b32, no branch, and (unlike a multiply by
 // 0/1) it also wipes NaN/inf, which keeps a diverged problem from leaking into its wave-mate

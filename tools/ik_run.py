@@ -21,6 +21,8 @@ if os.environ.get("IK_EXPRESS"):
     lib.bmpc_ik_set_express_capacity(int(os.environ["IK_EXPRESS"]))
 if os.environ.get("IK_EXPRESS_NEAR"):
     lib.bmpc_ik_set_express_near(float(os.environ["IK_EXPRESS_NEAR"]))
+if os.environ.get("IK_FUSED_DIRECT"):
+    lib.bmpc_ik_set_fused_direct_max(int(os.environ["IK_FUSED_DIRECT"]))
 if os.environ.get("IK_BLOCKING_WAITS"):
     lib.bmpc_ik_set_blocking_waits(int(os.environ["IK_BLOCKING_WAITS"]))
 robot = "go2" if cfg == "go2_h60" else "solo12"
