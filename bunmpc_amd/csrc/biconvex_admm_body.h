@@ -387,7 +387,7 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
                         UNROLL for (int l = 0; l < 9; ++l) {
                             const R g = fmaR(qd[l], y[l], fmaR(rho, z[l], q[l]));
                             R v = fmaR(-g, invL, y[l]);
-                            if (l < NB) v = fmaxR(fminR(v, ub[l]), lb[l]);
+                            if (l < NB) v = clamp_box(v, lb[l], ub[l]);
                             xn[l] = v;
                         }
                     }

@@ -85,6 +85,31 @@ __device__ __forceinline__ void seg_sum2(double &a, double &b) {
     }
 }
 
+// The two decisions of a FISTA step -- retry (cv > (L/2) g2) and exit (g2 < tol^2) -- from WAVE sums of g2 and cv taken in fp32:
+// 4 DPP-fused v_add_f32 per value, one v_permlane16_swap that leaves the sums of g2 in rows 0 / 2 and of cv in rows 1 / 3, one
+// v_permlane32_swap, two v_readlane: 19 instructions against the 36 of the fp64 butterfly (seg_sum2<64>).  The fp32 sums of
+// non-negative terms are within 5e-7 of the exact ones; a decision is taken from them only when both comparisons are clear of
+// their thresholds by more than 1e-5 (relative) and the sums are of ordinary size -- the caller falls back to the fp64
+// butterfly and the reference expression otherwise (returns false), so every decision is the one fp64 arithmetic makes.
+__device__ __forceinline__ bool banded_decisions(double g2, double cv, double Lh, double tol2, bool &retry, bool &finished) {
+    float a = (float)g2, b = (float)cv;
+    a += dpp_mov<DPP_QUAD_XOR1>(a); b += dpp_mov<DPP_QUAD_XOR1>(b);
+    a += dpp_mov<DPP_QUAD_XOR2>(a); b += dpp_mov<DPP_QUAD_XOR2>(b);
+    a += dpp_mov<DPP_ROW_HALF_MIRROR>(a); b += dpp_mov<DPP_ROW_HALF_MIRROR>(b);
+    a += dpp_mov<DPP_ROW_MIRROR>(a); b += dpp_mov<DPP_ROW_MIRROR>(b);
+    auto x = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    const float s = __uint_as_float(x[0]) + __uint_as_float(x[1]);        // rows 0, 2: g2 over a row pair; rows 1, 3: cv
+    auto y = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    const float w = __uint_as_float(y[0]) + __uint_as_float(y[1]);
+    const float g2w = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w), 0));
+    const float cvw = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w), 16));
+    const double g2s = (double)g2w, cvs = (double)cvw, rhs = Lh * g2s;
+    retry = cvs > rhs;
+    finished = g2s < tol2;
+    const bool ordinary = g2w > 1e-30f && g2w < 1e30f && cvw < 1e30f;
+    return ordinary && fabs(cvs - rhs) > 1e-5 * rhs && fabs(g2s - tol2) > 1e-5 * tol2;
+}
+
 // element of a global array: wave-uniform base + 32-bit per-lane byte offset (global_load v, v_off, s[base:base+1])
 __device__ __forceinline__ const double *at(const double *ubase, unsigned byte_off) {
     return reinterpret_cast<const double *>(reinterpret_cast<const char *>(ubase) + byte_off);
@@ -129,6 +154,17 @@ __device__ __forceinline__ double fmaxR(double a, double b) { return __builtin_f
 __device__ __forceinline__ float fmaxR(float a, float b) { return __builtin_fmaxf(a, b); }
 __device__ __forceinline__ double fminR(double a, double b) { return __builtin_fmin(a, b); }
 __device__ __forceinline__ float fminR(float a, float b) { return __builtin_fminf(a, b); }
+
+// The box projection max(min(v, hi), lo) as the two bare instructions.  Through fmin / fmax hipcc re-quiets the bounds inside
+// the FISTA loop (`v_max_f64 x, x, x` in front of every min / max: six extra instructions per motion iteration), although
+// they are loop constants quieted once outside; the instructions themselves return the non-NaN operand, as minnum / maxnum do.
+__device__ __forceinline__ double clamp_box(double v, double lo, double hi) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(v), "v"(hi));
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(r), "v"(lo));
+    return r;
+}
+__device__ __forceinline__ float clamp_box(float v, float lo, float hi) { return fmaxR(fminR(v, hi), lo); }
 
 constexpr double kGravity = 9.81;  // centroidal.cpp:63
 

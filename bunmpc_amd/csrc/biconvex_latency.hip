@@ -117,6 +117,8 @@ __global__ __launch_bounds__(64) void biconvex_latency_kernel(const BatchArgs a)
             applyA(y, ry);
             UNROLL for (int k = 0; k < 6; ++k) ra[k] = ry[k];
             const double mu2 = mu * mu, imu = 1.0 / (mu * mu + 1.0);
+            // the fp32 shortcut of the step decisions (banded_decisions) presumes sums of non-negative terms
+            const bool banded_f = rho >= 0.0 && !__any(wf[0] < 0 || wf[1] < 0 || wf[2] < 0 || wf[3] < 0 || wf[4] < 0 || wf[5] < 0);
             double invL = 2.0 * (1.0 / L_f);      // the gradient is carried as half of itself (biconvex_admm.hip)
             const double e2w = fh == 0 ? rho : 0.0;   // the residual rows are held twice: counted once
             bool act = true;
@@ -167,15 +169,19 @@ __global__ __launch_bounds__(64) void biconvex_latency_kernel(const BatchArgs a)
                     }
                     UNROLL for (int k = 0; k < 6; ++k) { const double e = rn[k] - ry[k]; e2 = fma(e, e, e2); }
                     cv = fma(e2w, e2, cv);
-                    double g2s = g2, cvs = cv;
-                    seg_sum2<64>(g2s, cvs);
-                    const double Lh = L_f * 0.5, rhs = Lh * g2s;     // fista.cpp:14-17, sqrt only where it could matter (biconvex_admm.hip)
-                    bool bt = cvs > rhs;
-                    done = g2s < tol2;
-                    if ((fabs(cvs - rhs) <= 1e-14 * rhs) || (fabs(g2s - tol2) <= 1e-14 * tol2)) {
-                        const double Gn = sqrt(g2s);
-                        bt = cvs > Lh * (Gn * Gn);
-                        done = Gn < tol;
+                    const double Lh = L_f * 0.5;
+                    bool bt;
+                    if (!(banded_f && banded_decisions(g2, cv, Lh, tol2, bt, done))) {
+                        double g2s = g2, cvs = cv;
+                        seg_sum2<64>(g2s, cvs);
+                        const double rhs = Lh * g2s;     // fista.cpp:14-17, sqrt only where it could matter (biconvex_admm.hip)
+                        bt = cvs > rhs;
+                        done = g2s < tol2;
+                        if ((fabs(cvs - rhs) <= 1e-14 * rhs) || (fabs(g2s - tol2) <= 1e-14 * tol2)) {
+                            const double Gn = sqrt(g2s);
+                            bt = cvs > Lh * (Gn * Gn);
+                            done = Gn < tol;
+                        }
                     }
                     if (!__any(bt)) break;
                     L_f *= beta; ++bt_f;
@@ -301,6 +307,7 @@ __global__ __launch_bounds__(64) void biconvex_latency_kernel(const BatchArgs a)
             double fy[3];
             UNROLL for (int k = 0; k < 3; ++k) fy[k] = bperm(ry[k], src2);
             double invL = 2.0 * (1.0 / L_x);
+            const bool banded_x = rho >= 0.0 && !__any(qd[0] < 0 || qd[1] < 0 || qd[2] < 0);
             bool act = true;
             auto iterate = [&](const double (&xo)[3], const double (&ro)[3], double (&xn)[3], double (&rn)[3], int i) {
                 const double cm = cmtab[i];
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(64) void biconvex_latency_kernel(const BatchArgs a)
                         UNROLL for (int k = 0; k < 3; ++k) z[k] += fma(a2[k], fy[k], fma(b2[k], fy[(k + 1) % 3], c2[k] * fy[(k + 2) % 3]));
                         UNROLL for (int k = 0; k < 3; ++k) {
                             const double g = fma(qd[k], y[k], fma(rho, z[k], q[k]));
-                            xn[k] = fmax(fmin(fma(-g, invL, y[k]), ub[k]), lb[k]);
+                            xn[k] = clamp_box(fma(-g, invL, y[k]), lb[k], ub[k]);
                         }
                     }
                     applyA(xn, rn);
@@ -324,15 +331,19 @@ __global__ __launch_bounds__(64) void biconvex_latency_kernel(const BatchArgs a)
                         e2 = fma(e, e, e2);
                     }
                     cv = fma(rho, e2, cv);
-                    double g2s = g2, cvs = cv;
-                    seg_sum2<64>(g2s, cvs);
-                    const double Lh = L_x * 0.5, rhs = Lh * g2s;
-                    bool bt = cvs > rhs;
-                    done = g2s < tol2;
-                    if ((fabs(cvs - rhs) <= 1e-14 * rhs) || (fabs(g2s - tol2) <= 1e-14 * tol2)) {
-                        const double Gn = sqrt(g2s);
-                        bt = cvs > Lh * (Gn * Gn);
-                        done = Gn < tol;
+                    const double Lh = L_x * 0.5;
+                    bool bt;
+                    if (!(banded_x && banded_decisions(g2, cv, Lh, tol2, bt, done))) {
+                        double g2s = g2, cvs = cv;
+                        seg_sum2<64>(g2s, cvs);
+                        const double rhs = Lh * g2s;
+                        bt = cvs > rhs;
+                        done = g2s < tol2;
+                        if ((fabs(cvs - rhs) <= 1e-14 * rhs) || (fabs(g2s - tol2) <= 1e-14 * tol2)) {
+                            const double Gn = sqrt(g2s);
+                            bt = cvs > Lh * (Gn * Gn);
+                            done = Gn < tol;
+                        }
                     }
                     if (!__any(bt)) break;
                     L_x *= beta; ++bt_x;

@@ -84,6 +84,10 @@ int check_batch(const bmpc_batch_t *d) {
     } else {
         if (!d->W_X || !d->W_X_ter || !d->W_F || !d->bounds || !d->X_nom || !d->X_ter)
             return fail(BMPC_BAD_ARG, "harness form needs W_X, W_X_ter, W_F, bounds, X_nom, X_ter");
+        // batch strides: 0 (one block shared by all problems) or the distance between two problems' blocks, in doubles.  The
+        // kernels reach the (at most four) problems of a wave by 32-bit byte offsets from the wave's first problem.
+        for (long stride : {d->sW_X, d->sW_X_ter, d->sW_F, d->sbounds})
+            if (stride < 0 || stride > (1L << 26)) return fail(BMPC_BAD_ARG, "batch stride of a weight / bounds array is negative or above 2^26 doubles");
     }
     return BMPC_OK;
 }

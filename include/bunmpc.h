@@ -105,7 +105,7 @@ int bmpc_biconvex_set_robot_mass(bmpc_biconvex_t *h, double m);
  * One kernel launch = B x BiConvexMP::optimize.  Array shapes, batch outermost:
  *   cnt_plan [B][H][E][4], dt [B][H], x_init [B][9]
  *   harness form (raw = 0): W_X [.][9H], W_X_ter [.][9], W_F [.][3EH], bounds [.][H][6]
- *       with batch strides s* in doubles (0 = one copy shared by the batch),
+ *       with batch strides s* in doubles (0 = one copy shared by the batch; at most 2^26),
  *       X_nom [B][9H], X_ter [B][9]      -- the kernel applies create_cost_X /
  *       create_cost_F / create_bound_constraints (biconvex.cpp:27-78) itself
  *   raw form (raw = 1): Qx, qx, lbx, ubx [B][9(H+1)], Qf [B][3EH], qf [B][3EH] or NULL

@@ -198,6 +198,17 @@ def test_unsupported_shapes_are_refused():
     assert bb.solve_host(problems.make_batch("solo12_trot", 1).slice(0, 0), num_iters=1)["X"].shape[0] == 0
 
 
+def test_fp32_variant_on_a_ragged_batch():
+    """The fp32 kernels are a translation unit of their own (biconvex_admm_f32.hip): the padding problems of a last, partly
+    filled wave (B = 7 at four problems per wave) read the wave's first problem and write nothing."""
+    b = problems.make_batch("solo12_trot", 7, H=8)
+    d64 = bb.solve_host(b, num_iters=3)
+    d32 = bb.solve_host(b, num_iters=3, precision="f32")
+    assert np.array_equal(d32["stats"][:, [0, 5]], d64["stats"][:, [0, 5]])
+    for k in ("X", "F"):
+        assert np.median(rel_l2(d32[k], d64[k])) < 1e-4 and rel_l2(d32[k], d64[k]).max() < 5e-3
+
+
 @pytest.mark.parametrize("which", ["batch", "wave"])
 def test_diverging_problem_does_not_poison_neighbours(oracle, mapping, which):
     """NaN handling (biconvex.cpp:106-109): a problem that blows up reports status 2 and NaNs;
