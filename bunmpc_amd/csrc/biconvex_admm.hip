@@ -43,10 +43,10 @@ namespace {
 
 #include "biconvex_admm_body.h"
 
-// fp64: ONE wave per SIMD.  The body holds 302-336 registers (314-370 when the measurement below was made); capped at 256 (two waves per SIMD) the compiler parks 60-90
-// values in scratch memory and the launch is 4 % faster (4.33 -> 4.17 ms at B = 4096) -- but the scratch of 2048 waves does
-// not stay in L2 and the kernel's HBM traffic goes from 39.5 MB (the inputs once, the results once) to 549 MB per launch
-// (PMC, FETCH_SIZE x 2 + WRITE_SIZE).  Not taken: the iterates-never-leave-the-chip property is worth more than 4 %.
+// fp64: ONE wave per SIMD.  The body holds 302-336 registers; capped at 256 (two waves per SIMD,
+// `__attribute__((amdgpu_waves_per_eu(2, 2)))`) the compiler parks 77-115 values in scratch memory.  Round 2 measured that build
+// 4 % faster at 14 x the HBM traffic (549 instead of 39.5 MB per launch: the scratch of 2048 waves does not stay in L2); against
+// this round's one-wave build it is level (4.11 vs 4.09 ms at B = 4096, 9.43 vs 9.30 ms on the Go2 shape).  Not taken.
 template <typename R, int LPP, int E, bool RAW, bool HASQF>
 __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) { admm_body<R, LPP, E, RAW, HASQF>(a); }
 __global__ __launch_bounds__(64) void lane_selftest_kernel(const double *in, double *out) {

@@ -4,6 +4,7 @@
 #pragma once
 
 #define UNROLL _Pragma("unroll")
+typedef unsigned long long mask_t;      // a 64-bit lane mask in scalar registers (see `lanes` at the end of this file)
 
 // DPP controls (LLVM SIDefines.h DppCtrl)
 constexpr int DPP_QUAD_XOR1 = 0xB1;     // quad_perm:[1,0,3,2]
@@ -173,6 +174,5 @@ constexpr double kGravity = 9.81;  // centroidal.cpp:63
 // combining them is scalar-unit work, and `lanes(m)` turns a mask back into a per-lane predicate (selects and branches take
 // the mask as it is).  As per-lane bools across loop iterations the compiler kept them as 0 / 1 in vector registers: a
 // dozen vector instructions per iteration of pure bookkeeping in an issue-bound kernel.
-typedef unsigned long long mask_t;
 __device__ __forceinline__ bool lanes(mask_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
