@@ -1,19 +1,24 @@
 #!/usr/bin/env python3
 """gpurun_out/{bench_<tag>.json, prof_<tag>/, pmc_<tag>_*} (tools/prof_round2.sh) -> profiles/<rnd>_* and profiles/pmc_traffic.json.
 usage: python tools/collect_round2.py <tag> <rnd, e.g. r02>"""
-import collections, csv, glob, json, re, shutil, sys
+import collections, csv, glob, json, os, re, shutil, sys
+
+
+def newest(pattern):
+    """a tag used twice leaves the earlier run's files beside the new ones (gpurun merges directories): take the latest"""
+    return max(glob.glob(pattern, recursive=True), key=os.path.getmtime)
 
 tag, rnd = sys.argv[1], sys.argv[2]
 bench = json.load(open("gpurun_out/bench_%s.json" % tag))
 shutil.copy("gpurun_out/bench_%s.json" % tag, "profiles/%s_bench.json" % rnd)
-stats = glob.glob("gpurun_out/prof_%s/**/*kernel_stats.csv" % tag, recursive=True)[0]
+stats = newest("gpurun_out/prof_%s/**/*kernel_stats.csv" % tag)
 rows = list(csv.DictReader(open(stats)))
 keep = [r for r in rows if "bunmpc" in r["Name"] or "copyBuffer" in r["Name"]]
 with open("profiles/%s_bench_kernel_stats.csv" % rnd, "w") as f:
     w = csv.DictWriter(f, fieldnames=rows[0].keys())
     w.writeheader()
     w.writerows(keep)
-trace = list(csv.DictReader(open(glob.glob("gpurun_out/prof_%s/**/*kernel_trace.csv" % tag, recursive=True)[0])))
+trace = list(csv.DictReader(open(newest("gpurun_out/prof_%s/**/*kernel_trace.csv" % tag))))
 name = "biconvex_admm_kernel<double, 32, 4, false, false>"
 h = sorted((r for r in trace if name in r["Kernel_Name"] and int(r["Grid_Size_X"]) == 2048 * 64), key=lambda r: int(r["Start_Timestamp"]))
 n_warm, n_timed = bench["warmup"], bench["steps"]
@@ -35,7 +40,7 @@ for w, key in keys.items():
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     solves = 3
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        f = glob.glob("gpurun_out/pmc_%s_%s_%s/**/*counter_collection.csv" % (tag, w, c), recursive=True)[0]
+        f = newest("gpurun_out/pmc_%s_%s_%s/**/*counter_collection.csv" % (tag, w, c))
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == c and "bunmpc" in r["Kernel_Name"]:
                 k = re.search(r"(\w+_kernel(<[^>]*>)?)", r["Kernel_Name"]).group(1)
