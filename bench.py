@@ -432,6 +432,9 @@ def biconvex_leg(D, args):
     achieved = abytes / (kern_ms * 1e-3) / 1e9
     flops = counts[2] / W  # per launch on one GPU
     wkey = "%s H=%d B=%d admm_iters=%d fista_maxit=%d %s" % (args.config, pb.H, B, args.admm_iters, args.maxit, args.precision)
+    # the kernel the dispatch took for this batch (small batches of short horizons go to the one-problem-per-wave kernel)
+    last_kernel = bb._lib.lib().bmpc_biconvex_last_kernel_name().decode()
+    last_kernel = {"biconvex_admm_kernel": "biconvex_admm_kernel<double>"}.get(last_kernel, last_kernel)
     prec = {"f64": "fp64", "f32": "fp32 iterates, fp64 decisions"}[args.precision]
     out = {
         "metric": "MPC solves/sec (batch, whole node), %s, %d ADMM iters, %s" % (METRIC_SHAPE.get(args.config, args.config), args.admm_iters, prec),
@@ -444,7 +447,7 @@ def biconvex_leg(D, args):
                    "global_batch": B * W, "parallelism": "batch-shard x%d" % W},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(wkey),
-                     "kernel": "biconvex_admm_kernel<double>" if args.precision == "f64" else "biconvex_admm_kernel_f32", "kernel_ms": kern_ms,
+                     "kernel": last_kernel, "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_launch": abytes,
                      "valu": {"model_flops_per_launch": flops,
                               "achieved_tflops": flops / (kern_ms * 1e-3) / 1e12,

@@ -85,6 +85,8 @@ hipError_t launch_lpp(const BatchArgs &a, hipStream_t stream) {
 
 static int g_latency_max_batch = 1024;
 int set_latency_mapping_max_batch(int max_batch) { const int old = g_latency_max_batch; g_latency_max_batch = max_batch; return old; }
+static int g_exact_step_decisions = 0;
+int set_exact_step_decisions(int on) { const int old = g_exact_step_decisions; g_exact_step_decisions = on; return old; }
 // which kernel the calling host thread's latest launch_biconvex_admm took (tests of the default dispatch; profiles)
 static thread_local const char *t_last_kernel = "";
 const char *biconvex_last_kernel_name() { return t_last_kernel; }
@@ -98,7 +100,12 @@ hipError_t launch_biconvex_admm(const BatchArgs &a, int n_eff, hipStream_t strea
     for (long stride : {a.sW_X, a.sW_X_ter, a.sW_F, a.sbounds})
         if (stride < 0 || stride > (1L << 26)) return hipErrorInvalidValue;
     // few problems, short horizon: one problem per wave (the chain of a solve is ~2.3x shorter; biconvex_latency.hip)
-    if (a.B <= g_latency_max_batch && latency_mapping_fits(a, n_eff)) { t_last_kernel = "biconvex_latency_kernel"; return launch_biconvex_latency(a, stream); }
+    if (a.B <= g_latency_max_batch && latency_mapping_fits(a, n_eff)) {
+        t_last_kernel = "biconvex_latency_kernel";
+        BatchArgs al = a;
+        al.exact_step_decisions = g_exact_step_decisions;
+        return launch_biconvex_latency(al, stream);
+    }
     const int k = a.H + 1;
     t_last_kernel = a.precision == 1 ? "biconvex_admm_kernel_f32" : "biconvex_admm_kernel";
     if (k <= 16) return launch_lpp<16>(a, stream);

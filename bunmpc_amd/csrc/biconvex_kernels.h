@@ -37,6 +37,7 @@ struct SolverConsts {
 struct BatchArgs {
     int B, H, raw, cold_start;
     int precision;   // 0: fp64 arithmetic; 1: fp32 iterates with fp64 decisions (harness form only)
+    int exact_step_decisions;   // 1: the one-problem-per-wave kernel skips the fp32 shortcut of its step decisions (tests)
     double L0_x, L0_f;
     SolverConsts c;
     const double *cnt_plan, *dt, *x_init;
@@ -61,6 +62,7 @@ hipError_t launch_biconvex_admm(const BatchArgs &a, int n_eff, hipStream_t strea
 bool latency_mapping_fits(const BatchArgs &a, int n_eff);
 hipError_t launch_biconvex_latency(const BatchArgs &a, hipStream_t stream);
 int set_latency_mapping_max_batch(int max_batch);   // returns the old value
+int set_exact_step_decisions(int on);                // ... takes every step decision from the fp64 sums; returns the old value
 
 // fp32 instantiations (biconvex_admm_f32.hip); called by launch_biconvex_admm with the lanes per problem (16 / 32 / 64), the grid
 // and the LDS bytes it has worked out

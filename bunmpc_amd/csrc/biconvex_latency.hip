@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64) void biconvex_latency_kernel(const BatchArgs a)
             UNROLL for (int k = 0; k < 6; ++k) ra[k] = ry[k];
             const double mu2 = mu * mu, imu = 1.0 / (mu * mu + 1.0);
             // the fp32 shortcut of the step decisions (banded_decisions) presumes sums of non-negative terms
-            const bool banded_f = rho >= 0.0 && !__any(wf[0] < 0 || wf[1] < 0 || wf[2] < 0 || wf[3] < 0 || wf[4] < 0 || wf[5] < 0);
+            const bool banded_f = !a.exact_step_decisions && rho >= 0.0 && !__any(wf[0] < 0 || wf[1] < 0 || wf[2] < 0 || wf[3] < 0 || wf[4] < 0 || wf[5] < 0);
             double invL = 2.0 * (1.0 / L_f);      // the gradient is carried as half of itself (biconvex_admm.hip)
             const double e2w = fh == 0 ? rho : 0.0;   // the residual rows are held twice: counted once
             bool act = true;
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64) void biconvex_latency_kernel(const BatchArgs a)
             double fy[3];
             UNROLL for (int k = 0; k < 3; ++k) fy[k] = bperm(ry[k], src2);
             double invL = 2.0 * (1.0 / L_x);
-            const bool banded_x = rho >= 0.0 && !__any(qd[0] < 0 || qd[1] < 0 || qd[2] < 0);
+            const bool banded_x = !a.exact_step_decisions && rho >= 0.0 && !__any(qd[0] < 0 || qd[1] < 0 || qd[2] < 0);
             bool act = true;
             auto iterate = [&](const double (&xo)[3], const double (&ro)[3], double (&xn)[3], double (&rn)[3], int i) {
                 const double cm = cmtab[i];

@@ -149,6 +149,11 @@ int bmpc_biconvex_solve_batch_host(const bmpc_batch_t *d);
  * chain of a solve is ~2.3x shorter), larger ones one knot per lane with 4 / 2 / 1 problems per wave.  Default 1024 (one
  * wave per SIMD of an MI355X); 0 = never.  Returns the old value. */
 int bmpc_set_latency_mapping_max_batch(int max_batch);
+/* The one-problem-per-wave kernel takes the two decisions of a FISTA step (retry, fista.cpp:16; exit, fista.cpp:29) from fp32
+ * wave sums whenever both comparisons are clear of their thresholds by 1e-5 relative, from the fp64 sums and the reference
+ * expression otherwise.  on = 1: always from the fp64 sums (a test switch: results must be bit-identical either way).
+ * Returns the old value. */
+int bmpc_set_exact_step_decisions(int on);
 /* symbol-name prefix of the kernel that serves (n_col, raw), for profiles */
 const char *bmpc_biconvex_kernel_name(int n_col, int raw);
 /* which kernel the calling host thread's latest batch solve was dispatched to: "biconvex_latency_kernel" (one problem per wave),

@@ -342,6 +342,32 @@ def test_latency_mapping_equals_batch_mapping_and_oracle(oracle, mapping, config
     assert np.array_equal(kw["L_x"], kb["L_x"]) and np.array_equal(kw["L_f"], kb["L_f"])
 
 
+def test_fp32_shortcut_of_the_step_decisions_changes_nothing(hiplib, mapping):
+    """The one-problem-per-wave kernel takes retry / exit decisions from fp32 wave sums when they are clear of their thresholds
+    (biconvex_lanes.h::banded_decisions).  With the shortcut switched off every decision comes from the fp64 sums: the two runs
+    must agree in EVERY BIT of every output -- full 10-iteration solves that pass through ~25 exits and a few thousand retry
+    tests per problem, step constants low enough to force retries, and a diverging problem (inf / NaN sums)."""
+    mapping("wave")
+    b = problems.make_batch("solo12_mixed", 64)
+    b.x_init[5, 2] = 1e200
+    b.X_nom[5] = 1e200
+    Lx = np.where(np.arange(64) % 3 == 0, 1e4, 2.25e6)
+    Lf = np.where(np.arange(64) % 4 == 0, 10.0, 506.25)
+    X0, F0, P0 = b.warm_start()
+
+    def run(exact):
+        old = hiplib.bmpc_set_exact_step_decisions(exact)
+        try:
+            return bb.solve_host(b, num_iters=10, warm=(X0, F0, P0), L_x=Lx, L_f=Lf, keep_hist=True)
+        finally:
+            hiplib.bmpc_set_exact_step_decisions(old)
+    fast, exact = run(0), run(1)
+    assert hiplib.bmpc_biconvex_last_kernel_name().decode() == "biconvex_latency_kernel"
+    for k in ("X", "F", "P", "L_x", "L_f", "stats", "hist", "dyn_viol"):
+        assert np.array_equal(fast[k], exact[k], equal_nan=True), k
+    assert fast["stats"][:, 3].sum() > 0 and fast["stats"][:, 4].sum() > 0 and fast["stats"][5, 5] == 2
+
+
 def test_latency_mapping_raw_form_warm_start_and_backtracking(oracle, mapping):
     """raw cost / bound arrays, warm start, per-problem L0 low enough to force retries in both FISTA loops, early exit, and a
     diverging problem -- all through the one-problem-per-wave kernel"""
