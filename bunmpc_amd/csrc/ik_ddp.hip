@@ -1610,7 +1610,11 @@ __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a
     if (threadIdx.x == 0) g_fwd.args = a;
     __syncthreads();
     const int wave = threadIdx.x >> 6;
-    if (wave == 0) forward_role<NW, forward_roles(NW, 0)>();
+    // The chain wave's role is the KERNEL's body, the other roles are calls: a called function saves and restores the callee-saved
+    // registers it uses (108 of the vector registers and every accumulation register from a32 on: 314 scratch stores at entry and
+    // 314 loads before the return for the chain role, which is the wave everybody waits for); one role inlined beside calls does
+    // not bring the interference back -- nothing is live across a call.
+    if (wave == 0) forward_body<NW, false, forward_roles(NW, 0)>(a, g_fwd.s, -1);
     else if (wave == 1) forward_role<NW, forward_roles(NW, 1)>();
     else forward_role<NW, forward_roles(NW, 2)>();
 }
