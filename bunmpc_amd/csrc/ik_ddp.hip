@@ -1806,8 +1806,10 @@ __global__ __launch_bounds__(256) void ik_fused_kernel(const IkBatchArgs a, cons
         const long long c1 = __builtin_readcyclecounter();
         cyc_a += c1 - c0; ticks += nt; ++turns;
         if (sc[S_DONE] != 0.0) break;       // the pass was given up at the regularisation's ceiling
-        if (wave == 0) fused_role_line_search<forward_roles(4, 0)>(b);
-        else if (wave == 1) fused_role_line_search<forward_roles(4, 1)>(b);
+        if (wave == 0) {       // the chain role inline, as in the line-search kernels (no callee-saved registers to save and restore)
+            forward_body<4, true, forward_roles(4, 0)>(a, s.fw, b);
+            if (threadIdx.x == 0) s.ctl.tele[3] += (long long)__builtin_readcyclecounter() - c1;
+        } else if (wave == 1) fused_role_line_search<forward_roles(4, 1)>(b);
         else if (wave == 2) fused_role_line_search<forward_roles(4, 2)>(b);
         else fused_role_line_search<forward_roles(4, 3)>(b);
         __syncthreads();
