@@ -1232,9 +1232,9 @@ __device__ __forceinline__ void fwd_sync() {
 // side by side (further rounds of four in the same call), nothing is appended to the active list, and no wave returns before
 // the last barrier.
 // ROLES (bit 0: the chain, bit 1: the robot walks and the residual costs, bit 2: the state-regularisation residual): what THIS wave
-// does, a compile-time constant.  The workgroup's waves run different instantiations of this one body, each as a non-inlined
-// function with a register allocation of its own (forward_role below): as run-time conditions inside one function the roles'
-// register arrays interfered in hipcc's allocator -- 512 registers and 124 spilled ones for code that needs half of that per role.
+// does, a compile-time constant.  The workgroup's waves run different instantiations of this one body (ik_forward_kernel below; in
+// the fused kernel the chain role inline, the others as non-inlined functions): as run-time conditions inside one instantiation
+// the roles' register arrays interfered in hipcc's allocator -- 512 registers and 124 spilled ones for code that needs half of that.
 constexpr int kRoleChain = 1, kRoleCost = 2, kRoleReg = 4;
 constexpr int forward_roles(int NW, int wave) {
     return NW == 1 ? 7 : wave == 0 ? (NW == 2 ? kRoleChain | kRoleReg : kRoleChain) : wave == 1 ? kRoleCost : (wave == 2 && NW >= 3) ? kRoleReg : 0;
@@ -1592,31 +1592,23 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
     }
 }
 
-// LDS of the line-search kernels, at file scope so that the role functions can name it (as g_fused, further down)
-struct alignas(16) ForwardShared { ForwardLds s; IkBatchArgs args; };
-__shared__ ForwardShared g_fwd;
-__device__ __forceinline__ IkBatchArgs uniform_args(const IkBatchArgs &g);      // every field through v_readfirstlane (defined with the fused kernel)
-template <int NW, int ROLES>
-__device__ __noinline__ void forward_role() {
-    const IkBatchArgs a = uniform_args(g_fwd.args);
-    forward_body<NW, false, ROLES>(a, g_fwd.s, -1);
-}
+// The line-search kernels.  Each wave's role is a separate INSTANTIATION of forward_body (ROLES a template constant), all of
+// them inline in the kernel behind a branch on the wave number.  History: with the roles as run-time conditions inside one
+// instantiation hipcc's allocator let their register arrays interfere (512 registers + 124 spilled); as non-inlined functions per
+// role that was gone, but a called function saves and restores the callee-saved registers it uses -- 314 scratch stores at entry
+// and 314 loads before the return for the chain role, ~18 us of every launch (Go2 forward pass 25.5 -> 23.7 ms with the chain
+// role inline); separate instantiations need no call at all (23.35 ms, no spills, 228-230 accumulation registers).
+__shared__ ForwardLds g_fwd;
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a) {
     if (NW == 1) {      // one wave does everything: nothing to separate
-        forward_body<1, false, 7>(a, g_fwd.s, -1);
+        forward_body<1, false, 7>(a, g_fwd, -1);
         return;
     }
-    if (threadIdx.x == 0) g_fwd.args = a;
-    __syncthreads();
     const int wave = threadIdx.x >> 6;
-    // The chain wave's role is the KERNEL's body, the other roles are calls: a called function saves and restores the callee-saved
-    // registers it uses (108 of the vector registers and every accumulation register from a32 on: 314 scratch stores at entry and
-    // 314 loads before the return for the chain role, which is the wave everybody waits for); one role inlined beside calls does
-    // not bring the interference back -- nothing is live across a call.
-    if (wave == 0) forward_body<NW, false, forward_roles(NW, 0)>(a, g_fwd.s, -1);
-    else if (wave == 1) forward_role<NW, forward_roles(NW, 1)>();
-    else forward_role<NW, forward_roles(NW, 2)>();
+    if (wave == 0) forward_body<NW, false, forward_roles(NW, 0)>(a, g_fwd, -1);
+    else if (wave == 1) forward_body<NW, false, forward_roles(NW, 1)>(a, g_fwd, -1);
+    else forward_body<NW, false, forward_roles(NW, 2)>(a, g_fwd, -1);
 }
 
 // ------------------------------------------------------------------------------ fused ---
