@@ -152,6 +152,14 @@ __device__ __forceinline__ long slot_problem(const IkBatchArgs &a, long slot) {
 // is only that the compiler keeps them in that order and that earlier LDS operations have completed.  __syncthreads() would
 // also wait for every outstanding GLOBAL load (s_waitcnt vmcnt(0)) -- here that is the prefetched L_xx row of the node, which
 // is not needed before the elimination and should keep flying across the exchanges in between.
+// Sum of one value per node, taken in the order SolverDDP::calcDiff adds the node costs (node 0 first): lane t holds node t's
+// value (T + 1 <= 64), every lane ends up with the sum.  v_readlane hands the values to the additions one by one.
+__device__ __forceinline__ double sum_nodes_in_turn(double mine, int T) {
+    double c = 0.0;
+    for (int t = 0; t <= T; ++t)
+        c += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), t), __builtin_amdgcn_readlane(__double2loint(mine), t));
+    return c;
+}
 __device__ __forceinline__ void wave_sync() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -835,7 +843,10 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
     if (recalc) {
         // SolverDDP::calcDiff tail: total cost and the gaps fs
         if (!FUSED) {
-            if (lane == 0) { double c = 0.0; for (int t = 0; t <= T; ++t) c += ws[L.fs + (long)t * kNDX]; sc[S_COST] = c; }
+            // (one lane adding T + 1 values it loads one after the other: a global-memory latency per node, ~0.6 us each -- 18 us of
+            // a 240 us pass at T = 30.  The loads go out side by side, one node per lane; the additions keep the reference's order.)
+            const double c = sum_nodes_in_turn(lane <= T ? ws[L.fs + (long)lane * kNDX] : 0.0, T);
+            if (lane == 0) sc[S_COST] = c;
             wave_sync();
         }
         if (!feas) {
@@ -1142,7 +1153,10 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
         tick_lds(tk);
         if (tk.dead) return;
         if (!gave_up && lane == kQuLane) sc[S_D2] = d2;
-        if (recalc && !gave_up && lane == 0) { double c = 0.0; for (int t = 0; t <= T; ++t) c += ctl->node_cost[t]; sc[S_COST] = c; }
+        if (recalc && !gave_up) {
+            const double c = sum_nodes_in_turn(lane <= T ? ctl->node_cost[lane] : 0.0, T);
+            if (lane == 0) sc[S_COST] = c;
+        }
         for (;;) {
             tick_lds(tk);
             if (tk.dead || tk.n >= lds_flag(ctl->done_tick)) break;
@@ -1271,6 +1285,9 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
     const bool all10 = all10_batch || (!FUSED && NW > 1 && spec && a.wide && pvalid && sc[S_WIDENOW] != 0.0);
     FwdSub &q = s.sub[si];
     bool live = pvalid && sc[S_DONE] == 0.0;     // this sub-group still has a line search to do
+    // (the problem's scalars in one go with the flag: a load behind the barrier below would be one more exposed memory latency)
+    const double cost = sc[S_COST], d1 = sc[S_D1], d2 = sc[S_D2];
+    const bool feas = sc[S_FEAS] != 0.0;
     if (!FUSED && !__any(live)) return;
     const int T = a.T, nn = a.T + 1;
     const int tslot = spec ? 4 * grp + si : 0;       // where this sub-group's trial trajectory goes
@@ -1290,8 +1307,6 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
     if (live && do_chain) stage_reg(0);
     fwd_sync<NW>();
     const RobotModelDev &m = s.m;
-    const double cost = sc[S_COST], d1 = sc[S_D1], d2 = sc[S_D2];
-    const bool feas = sc[S_FEAS] != 0.0;
     const double *state_w = q.sw, *ctrl_w = q.cw, *x_reg = q.xreg;
     const double *gtasks = a.tasks + bb * nn * kNodeTaskDoubles, *gdt = a.dt + bb * T;
     const bool owner = live;            // sub-groups that take part at all
