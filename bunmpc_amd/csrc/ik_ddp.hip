@@ -826,6 +826,7 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
     bool feas = sc[S_FEAS] != 0.0;
     const bool wasfeas = sc[S_WASFEAS] != 0.0;
     const bool recalc = sc[S_RECALC] != 0.0;
+    double xreg = sc[S_XREG];       // (with the flags: read further down it is one more memory latency in front of the first node)
     for (int i = lane; i < NWB * kPadRows * LDK; i += 64) s.Ys[0][i] = 0.0;                  // the padding of the MFMA operand image(s)
     for (int i = kNDX * LD + lane; i < kPadRows * LD + 16; i += 64) s.N[i] = 0.0;
     int hand = 0;       // NWB = 2: nodes handed to the gains wave so far (buffer = hand & 1)
@@ -876,7 +877,6 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
     const int uq = ul ? lane - kNV : 0;
     const unsigned row_addr = lds_offset(s.N + r * LD), col_addr = lds_offset(s.N + r);
     const unsigned a6_addr = lds_offset(s.A6), b6_addr = lds_offset(s.B6), fs_addr = lds_offset(s.fs);
-    double xreg = sc[S_XREG];
     double d1, d2, st;
 #ifdef BWD_PROFILE
     long long pc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pt0;
