@@ -33,7 +33,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # result does not depend on how it was scheduled" holds by construction.
 # biconvex_admm_f32.hip: no SLP vectoriser -- packed fp32 operations cost this kernel ~90 registers and its two-waves-per-SIMD
 # build 40-60 values in scratch memory (the reasons and the measurement are in the file's header).
-FILE_FLAGS = {"ik_ddp.hip": ["-ffp-contract=on"], "biconvex_admm_f32.hip": ["-fno-slp-vectorize"]}
+# -amdgpu-sched-strategy=max-ilp (the scheduler orders for instruction-level parallelism instead of register pressure): the
+# one-problem-per-wave kernel is one long dependent chain per wave, batch-1 p50 1.49 -> 1.455 ms; the fp32 kernel 6.03 -> 5.97 ms.
+# Timed and NOT taken elsewhere: the fp64 batch kernel (headline 4.095 -> 4.12 ms; its 64-lane shape 9.39 -> 9.24 ms) and ik_ddp.hip
+# (derivative pass -2 %, Riccati pass and line search +1.5 %).
+FILE_FLAGS = {"ik_ddp.hip": ["-ffp-contract=on"],
+              "biconvex_admm_f32.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+              "biconvex_latency.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def is_stale():
