@@ -37,7 +37,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # one-problem-per-wave kernel is one long dependent chain per wave, batch-1 p50 1.49 -> 1.455 ms; the fp32 kernel 6.03 -> 5.97 ms.
 # Timed and NOT taken elsewhere: the fp64 batch kernel (headline 4.095 -> 4.12 ms; its 64-lane shape 9.39 -> 9.24 ms) and ik_ddp.hip
 # (derivative pass -2 %, Riccati pass and line search +1.5 %).
+# -amdgpu-use-amdgpu-trackers (the scheduler follows register pressure with the target's own trackers): fp64 batch kernel, headline
+# 4.095 -> 4.007 ms, its 64-lane shape 9.39 -> 8.95 ms; worse on ik_ddp.hip (Riccati pass +5 %) and on the one-problem-per-wave
+# kernel (1.452 -> 1.469 ms), level on the fp32 kernel.  -amdgpu-schedule-metric-bias=0: no effect anywhere.
 FILE_FLAGS = {"ik_ddp.hip": ["-ffp-contract=on"],
+              "biconvex_admm.hip": ["-mllvm", "-amdgpu-use-amdgpu-trackers"],
               "biconvex_admm_f32.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"],
               "biconvex_latency.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
