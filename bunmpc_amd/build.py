@@ -39,9 +39,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # (derivative pass -2 %, Riccati pass and line search +1.5 %).
 # -amdgpu-use-amdgpu-trackers (the scheduler follows register pressure with the target's own trackers): fp64 batch kernel, headline
 # 4.095 -> 4.007 ms, its 64-lane shape 9.39 -> 8.95 ms; worse on ik_ddp.hip (Riccati pass +5 %) and on the one-problem-per-wave
-# kernel (1.452 -> 1.469 ms), level on the fp32 kernel.  -amdgpu-schedule-metric-bias=0: no effect anywhere.
+# kernel (1.452 -> 1.469 ms), level on the fp32 kernel.  With it -amdgpu-disable-unclustered-high-rp-reschedule (no second scheduling
+# pass against register pressure -- the kernel has 512 registers to itself): headline 4.014 -> 3.98 ms (64-lane shape 8.95 -> 9.0).
+# No effect or worse on top: -amdgpu-schedule-metric-bias=0, -amdgpu-schedule-relaxed-occupancy, -amdgpu-early-ifcvt, max-ilp,
+# -amdgpu-disable-clustered-low-occupancy-reschedule.
 FILE_FLAGS = {"ik_ddp.hip": ["-ffp-contract=on"],
-              "biconvex_admm.hip": ["-mllvm", "-amdgpu-use-amdgpu-trackers"],
+              "biconvex_admm.hip": ["-mllvm", "-amdgpu-use-amdgpu-trackers", "-mllvm", "-amdgpu-disable-unclustered-high-rp-reschedule"],
               "biconvex_admm_f32.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"],
               "biconvex_latency.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
