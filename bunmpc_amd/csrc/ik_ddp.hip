@@ -1196,10 +1196,10 @@ static_assert(kTrySlots >= 3 * kFwdSub - 2, "one trial slot per step length in t
 // Every vector a lane reads as a whole is 16-byte aligned and padded to the length of the batch reader that fetches it
 // (lds_batch.h): read element by element, each LDS read waits out its own latency in front of its first use.
 struct alignas(16) FwdSub {
-    double dx[kNDX], u[22], x[40], xn[40]; double part[kLegs + 1][10 + 3 * kFrameSlots]; double bc[4];
+    double dx[kNDX], u[22], x[40], xn[40]; double part[2][kLegs + 1][10 + 3 * kFrameSlots]; double bc[2][4];      // [node parity]
     // copies of what every node reads from HBM: per problem (regularisation reference and weights), per node (task block,
     // dt, the nominal state the feedback is taken around) -- the per-node ones are fetched one node ahead
-    double xreg[40], sw[kNDX], cw[22], tk[kNodeTaskDoubles + 3], xs[40];
+    double xreg[40], sw[kNDX], cw[22], tk[2][kNodeTaskDoubles + 3], xs[40];     // tk: [node parity]
 };
 static_assert((10 + 3 * kFrameSlots) % 2 == 0 && kNodeTaskDoubles % 2 == 1, "FwdSub members stay 16-byte aligned");
 __device__ __forceinline__ void lds_read_vec40(const double *p, double (&o)[40]) {
@@ -1249,14 +1249,24 @@ __device__ __forceinline__ void fwd_sync() {
 // does, a compile-time constant.  The workgroup's waves run different instantiations of this one body (ik_forward_kernel below; in
 // the fused kernel the chain role inline, the others as non-inlined functions): as run-time conditions inside one instantiation
 // the roles' register arrays interfered in hipcc's allocator -- 512 registers and 124 spilled ones for code that needs half of that.
-constexpr int kRoleChain = 1, kRoleCost = 2, kRoleReg = 4;
+// With three waves or more the robot walk of a node and the sum of its parts (totals, residuals, costs: one lane's serial work,
+// about as long as the walk) are on DIFFERENT waves, the sum one node behind the walk: the walk wave was the one the others waited
+// for at every node (10.5K cycles against the chain's 8.4K, tools/bwd_profile.py), now each half is shorter than the chain.  What
+// a node leaves for the node after it -- the parts, the cost terms, the task block -- is therefore kept per node PARITY in LDS,
+// and the node costs enter the trial's cost one node late (same order, same sum).
+constexpr int kRoleChain = 1, kRoleCost = 2, kRoleReg = 4, kRoleSum = 8;
 constexpr int forward_roles(int NW, int wave) {
-    return NW == 1 ? 7 : wave == 0 ? (NW == 2 ? kRoleChain | kRoleReg : kRoleChain) : wave == 1 ? kRoleCost : (wave == 2 && NW >= 3) ? kRoleReg : 0;
+    return NW == 1 ? 15
+         : NW == 2 ? (wave == 0 ? kRoleChain | kRoleReg : kRoleCost | kRoleSum)
+         : NW == 3 ? (wave == 0 ? kRoleChain : wave == 1 ? kRoleCost : kRoleReg | kRoleSum)
+                   : (wave == 0 ? kRoleChain : wave == 1 ? kRoleCost : wave == 2 ? kRoleReg : kRoleSum);
 }
 template <int NW, bool FUSED, int ROLES>
 __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s, long b_fused) {
     const int lane = threadIdx.x & 63, wave = NW > 1 ? (int)(threadIdx.x >> 6) : 0, si = lane / kFwdLanes, l = lane % kFwdLanes;
-    constexpr bool do_chain = (ROLES & kRoleChain) != 0, do_cost = (ROLES & kRoleCost) != 0, do_reg = (ROLES & kRoleReg) != 0;
+    constexpr bool do_chain = (ROLES & kRoleChain) != 0, do_cost = (ROLES & kRoleCost) != 0, do_reg = (ROLES & kRoleReg) != 0,
+                   do_sum = (ROLES & kRoleSum) != 0;
+    constexpr bool kSplit = NW >= 3;       // the sum of a node's parts runs on another wave than its walk, one node behind
     const bool spec = FUSED || a.fwd_spec != 0;
     // fwd_spec == 4: THREE workgroups per problem, workgroup g trying step lengths 2^-(4g + s): all ten in one round, on
     // separate CUs (inside one workgroup the register budget of seven waves did not allow it, EXPERIMENTS.md 9); the last of the
@@ -1329,8 +1339,8 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
         if (run && do_chain) {
             if (per_node && round > 0) stage_reg(0);
             for (int i = l; i < kNX; i += kFwdLanes) { q.x[i] = ws[L.xs_try + i]; q.xs[i] = ws[L.xs + i]; }   // x0 sits in slot 0
-            for (int i = l; i < kNodeTaskDoubles; i += kFwdLanes) q.tk[i] = gtasks[i];
-            if (l == 0) q.tk[kNodeTaskDoubles] = gdt[0];
+            for (int i = l; i < kNodeTaskDoubles; i += kFwdLanes) q.tk[0][i] = gtasks[i];
+            if (l == 0) q.tk[0][kNodeTaskDoubles] = gdt[0];
         }
         // feedback rows of node 0 (lanes 0..8 own rows l and l + 9): fetched one node ahead of their use from here on
         double kp0[kNDX], kp1[kNDX], up0 = 0.0, up1 = 0.0, fp0 = 0.0, fp1 = 0.0;
@@ -1340,15 +1350,18 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
             up0 = ws[L.us + l]; up1 = ws[L.us + l + 9]; fp0 = ws[L.kff + l]; fp1 = ws[L.kff + l + 9];
         }
         fwd_sync<NW>();
-        for (int t = 0; t <= T; ++t) {   // t == T: terminal node (cost only)
+        double dt_behind = 0.0;          // kSplit: the time step of the node whose cost is taken in at this node
+        for (int t = 0; t <= T + (kSplit ? 1 : 0); ++t) {   // t == T: terminal node (cost only); kSplit: one more turn for its sum
             if (!__any(run)) break;
+            const bool body = t <= T;           // a node to evaluate (false in the extra turn)
+            const int p = t & 1, ts = kSplit ? t - 1 : t, ps_ = ts & 1;       // ts: the node whose parts are summed / whose cost is taken in
 #ifdef BWD_PROFILE
             const long long fnode0 = __builtin_readcyclecounter();
             fpt = fnode0;
 #endif
-            const bool terminal = t == T;
-            NodeTasks tk{q.tk};
-            const double dtn = terminal ? 0.0 : q.tk[kNodeTaskDoubles];
+            const bool terminal = t >= T;
+            NodeTasks tk{q.tk[p]};
+            const double dtn = terminal ? 0.0 : q.tk[p][kNodeTaskDoubles];
             // next node's task block / dt / nominal state: requested now, parked in LDS at the end of this node
             double ntk[3] = {0.0, 0.0, 0.0}, nxs[3] = {0.0, 0.0, 0.0};
             if (run && do_chain && !terminal) {
@@ -1362,7 +1375,7 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
             }
             // phase 1: dx = xs[t] (-) x on lane 0 (feeds the feedback) and the state regularisation residual x_reg (-) x on
             // lane 5 (feeds the cost) -- one instruction stream when one wave does both
-            const bool want_dx = do_chain && l == 0 && !terminal, want_rs = do_reg && l == 5 && tk.state_w() != 0.0;
+            const bool want_dx = do_chain && l == 0 && !terminal, want_rs = do_reg && l == 5 && body && tk.state_w() != 0.0;
             if (run && (want_dx || want_rs)) {
                 double d[kNDX], xa[40], xb[40];
                 lds_read_vec40(want_dx ? q.xs : x_reg, xa);
@@ -1373,26 +1386,26 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
                     double acc = 0.0, swv[kNDX];
                     lds_read_vec36(state_w, swv);
                     UNROLL_RBD for (int i = 0; i < kNDX; ++i) acc += swv[i] * d[i] * d[i];
-                    q.bc[2] = tk.state_w() * 0.5 * acc;
+                    q.bc[p][2] = tk.state_w() * 0.5 * acc;
                 }
-            } else if (run && do_reg && l == 5) q.bc[2] = 0.0;
+            } else if (run && do_reg && l == 5 && body) q.bc[p][2] = 0.0;
             FSTAMP(0)
             // phase 2 (needs x only): the robot walk.  With a wave of its own (NW > 1) on all 16 lanes of the sub-group -- lane
             // 4 leg + j takes joint j of the leg, lane 3 the base body (rbd_quad.h::quad_part16); on the shared wave of the
             // many-problems mapping legs on lanes 0..3, base body on lane 4
             if (NW > 1) {
-                if (run && do_cost) {
+                if (run && do_cost && body) {
                     int fid[kFrameSlots];
                     UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) fid[f] = tk.frame_w(f) != 0.0 ? tk.frame_id(f) : -1;
                     PartSum ps;
                     quad_part16(m, q.x, fid, l, ps);
                     const int row = l == 3 ? kLegs : ((l & 3) == 0 ? (l >> 2) : -1);
                     if (row >= 0) {
-                        q.part[row][0] = ps.mass;
-                        UNROLL_RBD for (int c = 0; c < 3; ++c) q.part[row][1 + c] = ps.h1[c];
-                        UNROLL_RBD for (int c = 0; c < 6; ++c) q.part[row][4 + c] = ps.hO[c];
+                        q.part[p][row][0] = ps.mass;
+                        UNROLL_RBD for (int c = 0; c < 3; ++c) q.part[p][row][1 + c] = ps.h1[c];
+                        UNROLL_RBD for (int c = 0; c < 6; ++c) q.part[p][row][4 + c] = ps.hO[c];
                         UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
-                            UNROLL_RBD for (int c = 0; c < 3; ++c) q.part[row][10 + 3 * f + c] = ps.fhit[f] ? ps.fx[f][c] : 0.0;
+                            UNROLL_RBD for (int c = 0; c < 3; ++c) q.part[p][row][10 + 3 * f + c] = ps.fhit[f] ? ps.fx[f][c] : 0.0;
                     }
                 }
             } else if (run && do_cost && l <= kLegs) {
@@ -1406,11 +1419,11 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
                     vj[j] = l == 0 ? xv[kNQ + 6 + j] : l == 1 ? xv[kNQ + 9 + j] : l == 2 ? xv[kNQ + 12 + j] : xv[kNQ + 15 + j];
                 }
                 quad_part(m, xv, qj, vj, fid, l, ps);
-                q.part[l][0] = ps.mass;
-                UNROLL_RBD for (int c = 0; c < 3; ++c) q.part[l][1 + c] = ps.h1[c];
-                UNROLL_RBD for (int c = 0; c < 6; ++c) q.part[l][4 + c] = ps.hO[c];
+                q.part[p][l][0] = ps.mass;
+                UNROLL_RBD for (int c = 0; c < 3; ++c) q.part[p][l][1 + c] = ps.h1[c];
+                UNROLL_RBD for (int c = 0; c < 6; ++c) q.part[p][l][4 + c] = ps.hO[c];
                 UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
-                    UNROLL_RBD for (int c = 0; c < 3; ++c) q.part[l][10 + 3 * f + c] = ps.fhit[f] ? ps.fx[f][c] : 0.0;
+                    UNROLL_RBD for (int c = 0; c < 3; ++c) q.part[p][l][10 + 3 * f + c] = ps.fhit[f] ? ps.fx[f][c] : 0.0;
             }
             FSTAMP(1)
             if (NW == 1) fwd_sync<NW>();   // with several waves each side hands over inside its own wave (LDS keeps a wave's order)
@@ -1431,7 +1444,7 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
             FSTAMP(2)
             if (NW == 1) fwd_sync<NW>();
             // phase 4: control cost + Euler step (lane 6)
-            if (run && do_chain && l == 6) {
+            if (run && do_chain && l == 6 && body) {
                 double acc = 0.0;
                 if (!terminal) {
                     double cwv[22], uv[22], xv[40];
@@ -1443,21 +1456,22 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
                     euler_step<false>(xv, uv, dtn, xn, nullptr, nullptr);
                     bool bad = false;
                     UNROLL_RBD for (int i = 0; i < kNX; ++i) { ws[xs_try + (long)(t + 1) * kNX + i] = xn[i]; q.xn[i] = xn[i]; bad = bad || !(fabs(xn[i]) < INFINITY); }
-                    q.bc[1] = bad ? 1.0 : 0.0;
-                } else q.bc[1] = 0.0;
-                q.bc[3] = tk.ctrl_w() * 0.5 * acc;
+                    q.bc[p][1] = bad ? 1.0 : 0.0;
+                } else q.bc[p][1] = 0.0;
+                q.bc[p][3] = tk.ctrl_w() * 0.5 * acc;
             }
             FSTAMP(3)
             if (NW == 1) fwd_sync<NW>();
             // phase 5: the parts added up: CoM, centroidal momentum, their residual costs (without the state / control terms)
-            if (run && do_cost && l == 0) {
+            if (run && do_sum && l == 0 && ts >= 0 && ts <= T) {
+                NodeTasks tk{q.tk[ps_]};         // (node ts's task block: this node's, or with kSplit the one before)
                 double M = 0.0, h1[3] = {0, 0, 0}, hO[6] = {0, 0, 0, 0, 0, 0}, fx[kFrameSlots][3];
                 UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) fx[f][0] = fx[f][1] = fx[f][2] = 0.0;
                 constexpr int kPw = 10 + 3 * kFrameSlots;      // 22 doubles per part: five parts = 44 + 44 + 22
                 double2_t pa0[22], pa1[22], pa2[11];
-                lds_read_b128x22(lds_offset(&q.part[0][0]), pa0);
-                lds_read_b128x22(lds_offset(&q.part[2][0]), pa1);
-                lds_read_b128x11(lds_offset(&q.part[4][0]), pa2);
+                lds_read_b128x22(lds_offset(&q.part[ps_][0][0]), pa0);
+                lds_read_b128x22(lds_offset(&q.part[ps_][2][0]), pa1);
+                lds_read_b128x11(lds_offset(&q.part[ps_][4][0]), pa2);
                 auto part_at = [&](int pa, int k) -> double {      // compile-time indices after unrolling
                     const int e = (pa % 2) * kPw + k;
                     const double2_t v2 = pa < 2 ? pa0[e >> 1] : pa < 4 ? pa1[e >> 1] : pa2[e >> 1];
@@ -1487,7 +1501,7 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
                     UNROLL_RBD for (int k = 0; k < 3; ++k) { const double r = w != 0.0 ? fx[f][k] - tk.frame_ref(f)[k] : 0.0; acc += r * r; }
                     c += w * 0.5 * acc;
                 }
-                q.bc[0] = c;
+                q.bc[ps_][0] = c;
             }
 #ifdef BWD_PROFILE
             { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); fwork += __builtin_readcyclecounter() - fnode0; }
@@ -1497,20 +1511,22 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
             fwait += __builtin_readcyclecounter() - fnode0;
 #endif
             if (run) {
-                double c = q.bc[0] + (q.bc[2] + q.bc[3]);     // node cost: residual terms + (state + control)
-                if (!terminal) c *= dtn;
-                const bool bad = q.bc[1] != 0.0 || !(fabs(c) < INFINITY);
-                ctry += c;
+                if (ts >= 0) {      // node ts's cost: residual terms + (state + control)
+                    double c = q.bc[ps_][0] + (q.bc[ps_][2] + q.bc[ps_][3]);
+                    if (ts != T) c *= kSplit ? dt_behind : dtn;
+                    if (q.bc[ps_][1] != 0.0 || !(fabs(c) < INFINITY)) run = false;      // tryStep threw: this step length is out
+                    ctry += c;
+                }
+                dt_behind = dtn;
                 if (!terminal && do_chain) {
                     if (per_node) stage_reg(t + 1);
                     for (int i = l; i < kNX; i += kFwdLanes) q.x[i] = q.xn[i];
                     UNROLL_RBD for (int k = 0; k < 3; ++k) {
                         const int i = l + kFwdLanes * k;
-                        if (i <= kNodeTaskDoubles) q.tk[i] = ntk[k];
+                        if (i <= kNodeTaskDoubles) q.tk[p ^ 1][i] = ntk[k];
                         if (i < kNX) q.xs[i] = nxs[k];
                     }
                 }
-                if (bad) run = false;       // tryStep threw: this step length is out
             }
             fwd_sync<NW>();
             FSTAMP(4)
@@ -1617,7 +1633,7 @@ __shared__ ForwardLds g_fwd;
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void ik_forward_kernel(const IkBatchArgs a) {
     if (NW == 1) {      // one wave does everything: nothing to separate
-        forward_body<1, false, 7>(a, g_fwd, -1);
+        forward_body<1, false, 15>(a, g_fwd, -1);
         return;
     }
     const int wave = threadIdx.x >> 6;
