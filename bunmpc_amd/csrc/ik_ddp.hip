@@ -1196,10 +1196,10 @@ static_assert(kTrySlots >= 3 * kFwdSub - 2, "one trial slot per step length in t
 // Every vector a lane reads as a whole is 16-byte aligned and padded to the length of the batch reader that fetches it
 // (lds_batch.h): read element by element, each LDS read waits out its own latency in front of its first use.
 struct alignas(16) FwdSub {
-    double dx[kNDX], u[22], x[40], xn[40]; double part[2][kLegs + 1][10 + 3 * kFrameSlots]; double bc[2][4];      // [node parity]
+    double dx[kNDX], u[22], x[2][40]; double part[2][kLegs + 1][10 + 3 * kFrameSlots]; double bc[3][4];      // x, part: [node parity]; bc: [node mod 3]
     // copies of what every node reads from HBM: per problem (regularisation reference and weights), per node (task block,
     // dt, the nominal state the feedback is taken around) -- the per-node ones are fetched one node ahead
-    double xreg[40], sw[kNDX], cw[22], tk[2][kNodeTaskDoubles + 3], xs[40];     // tk: [node parity]
+    double xreg[40], sw[kNDX], cw[22], tk[3][kNodeTaskDoubles + 3], xs[40];     // tk: [node mod 3]
 };
 static_assert((10 + 3 * kFrameSlots) % 2 == 0 && kNodeTaskDoubles % 2 == 1, "FwdSub members stay 16-byte aligned");
 __device__ __forceinline__ void lds_read_vec40(const double *p, double (&o)[40]) {
@@ -1338,7 +1338,7 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
         double ctry = 0.0;
         if (run && do_chain) {
             if (per_node && round > 0) stage_reg(0);
-            for (int i = l; i < kNX; i += kFwdLanes) { q.x[i] = ws[L.xs_try + i]; q.xs[i] = ws[L.xs + i]; }   // x0 sits in slot 0
+            for (int i = l; i < kNX; i += kFwdLanes) { q.x[0][i] = ws[L.xs_try + i]; q.xs[i] = ws[L.xs + i]; }   // x0 sits in slot 0
             for (int i = l; i < kNodeTaskDoubles; i += kFwdLanes) q.tk[0][i] = gtasks[i];
             if (l == 0) q.tk[0][kNodeTaskDoubles] = gdt[0];
         }
@@ -1355,13 +1355,14 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
             if (!__any(run)) break;
             const bool body = t <= T;           // a node to evaluate (false in the extra turn)
             const int p = t & 1, ts = kSplit ? t - 1 : t, ps_ = ts & 1;       // ts: the node whose parts are summed / whose cost is taken in
+            const int m3 = t % 3, m3n = (t + 1) % 3, m3s = kSplit ? (t + 2) % 3 : m3;     // this node's, the next node's, node ts's slot of three
 #ifdef BWD_PROFILE
             const long long fnode0 = __builtin_readcyclecounter();
             fpt = fnode0;
 #endif
             const bool terminal = t >= T;
-            NodeTasks tk{q.tk[p]};
-            const double dtn = terminal ? 0.0 : q.tk[p][kNodeTaskDoubles];
+            NodeTasks tk{q.tk[m3]};
+            const double dtn = terminal ? 0.0 : q.tk[m3][kNodeTaskDoubles];
             // next node's task block / dt / nominal state: requested now, parked in LDS at the end of this node
             double ntk[3] = {0.0, 0.0, 0.0}, nxs[3] = {0.0, 0.0, 0.0};
             if (run && do_chain && !terminal) {
@@ -1379,16 +1380,16 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
             if (run && (want_dx || want_rs)) {
                 double d[kNDX], xa[40], xb[40];
                 lds_read_vec40(want_dx ? q.xs : x_reg, xa);
-                lds_read_vec40(q.x, xb);
+                lds_read_vec40(q.x[p], xb);
                 state_diff_q(xa, xb, d);
                 if (want_dx) { UNROLL_RBD for (int i = 0; i < kNDX; ++i) q.dx[i] = d[i]; }
                 else {
                     double acc = 0.0, swv[kNDX];
                     lds_read_vec36(state_w, swv);
                     UNROLL_RBD for (int i = 0; i < kNDX; ++i) acc += swv[i] * d[i] * d[i];
-                    q.bc[p][2] = tk.state_w() * 0.5 * acc;
+                    q.bc[m3][2] = tk.state_w() * 0.5 * acc;
                 }
-            } else if (run && do_reg && l == 5 && body) q.bc[p][2] = 0.0;
+            } else if (run && do_reg && l == 5 && body) q.bc[m3][2] = 0.0;
             FSTAMP(0)
             // phase 2 (needs x only): the robot walk.  With a wave of its own (NW > 1) on all 16 lanes of the sub-group -- lane
             // 4 leg + j takes joint j of the leg, lane 3 the base body (rbd_quad.h::quad_part16); on the shared wave of the
@@ -1398,7 +1399,7 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
                     int fid[kFrameSlots];
                     UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) fid[f] = tk.frame_w(f) != 0.0 ? tk.frame_id(f) : -1;
                     PartSum ps;
-                    quad_part16(m, q.x, fid, l, ps);
+                    quad_part16(m, q.x[p], fid, l, ps);
                     const int row = l == 3 ? kLegs : ((l & 3) == 0 ? (l >> 2) : -1);
                     if (row >= 0) {
                         q.part[p][row][0] = ps.mass;
@@ -1413,7 +1414,7 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
                 UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) fid[f] = tk.frame_w(f) != 0.0 ? tk.frame_id(f) : -1;
                 PartSum ps;
                 double xv[40], qj[kLegJoints], vj[kLegJoints];
-                lds_read_vec40(q.x, xv);
+                lds_read_vec40(q.x[p], xv);
                 UNROLL_RBD for (int j = 0; j < kLegJoints; ++j) {      // this lane's leg out of the four, by selects (no indexed registers)
                     qj[j] = l == 0 ? xv[7 + j] : l == 1 ? xv[10 + j] : l == 2 ? xv[13 + j] : xv[16 + j];
                     vj[j] = l == 0 ? xv[kNQ + 6 + j] : l == 1 ? xv[kNQ + 9 + j] : l == 2 ? xv[kNQ + 12 + j] : xv[kNQ + 15 + j];
@@ -1450,21 +1451,21 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
                     double cwv[22], uv[22], xv[40];
                     lds_read_vec22(ctrl_w, cwv);
                     lds_read_vec22(q.u, uv);
-                    lds_read_vec40(q.x, xv);
+                    lds_read_vec40(q.x[p], xv);
                     UNROLL_RBD for (int i = 0; i < kNV; ++i) acc += cwv[i] * uv[i] * uv[i];
                     double xn[kNX];
                     euler_step<false>(xv, uv, dtn, xn, nullptr, nullptr);
                     bool bad = false;
-                    UNROLL_RBD for (int i = 0; i < kNX; ++i) { ws[xs_try + (long)(t + 1) * kNX + i] = xn[i]; q.xn[i] = xn[i]; bad = bad || !(fabs(xn[i]) < INFINITY); }
-                    q.bc[p][1] = bad ? 1.0 : 0.0;
-                } else q.bc[p][1] = 0.0;
-                q.bc[p][3] = tk.ctrl_w() * 0.5 * acc;
+                    UNROLL_RBD for (int i = 0; i < kNX; ++i) { ws[xs_try + (long)(t + 1) * kNX + i] = xn[i]; q.x[p ^ 1][i] = xn[i]; bad = bad || !(fabs(xn[i]) < INFINITY); }
+                    q.bc[m3][1] = bad ? 1.0 : 0.0;
+                } else q.bc[m3][1] = 0.0;
+                q.bc[m3][3] = tk.ctrl_w() * 0.5 * acc;
             }
             FSTAMP(3)
             if (NW == 1) fwd_sync<NW>();
             // phase 5: the parts added up: CoM, centroidal momentum, their residual costs (without the state / control terms)
             if (run && do_sum && l == 0 && ts >= 0 && ts <= T) {
-                NodeTasks tk{q.tk[ps_]};         // (node ts's task block: this node's, or with kSplit the one before)
+                NodeTasks tk{q.tk[m3s]};         // (node ts's task block: this node's, or with kSplit the one before)
                 double M = 0.0, h1[3] = {0, 0, 0}, hO[6] = {0, 0, 0, 0, 0, 0}, fx[kFrameSlots][3];
                 UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) fx[f][0] = fx[f][1] = fx[f][2] = 0.0;
                 constexpr int kPw = 10 + 3 * kFrameSlots;      // 22 doubles per part: five parts = 44 + 44 + 22
@@ -1501,7 +1502,10 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
                     UNROLL_RBD for (int k = 0; k < 3; ++k) { const double r = w != 0.0 ? fx[f][k] - tk.frame_ref(f)[k] : 0.0; acc += r * r; }
                     c += w * 0.5 * acc;
                 }
-                q.bc[ps_][0] = c;
+                q.bc[m3s][0] = c;
+            }
+            if (run && do_chain && !terminal) {      // the next node's task block, requested at the top of this node
+                UNROLL_RBD for (int k = 0; k < 3; ++k) { const int i = l + kFwdLanes * k; if (i <= kNodeTaskDoubles) q.tk[m3n][i] = ntk[k]; }
             }
 #ifdef BWD_PROFILE
             { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); fwork += __builtin_readcyclecounter() - fnode0; }
@@ -1512,23 +1516,21 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
 #endif
             if (run) {
                 if (ts >= 0) {      // node ts's cost: residual terms + (state + control)
-                    double c = q.bc[ps_][0] + (q.bc[ps_][2] + q.bc[ps_][3]);
+                    double c = q.bc[m3s][0] + (q.bc[m3s][2] + q.bc[m3s][3]);
                     if (ts != T) c *= kSplit ? dt_behind : dtn;
-                    if (q.bc[ps_][1] != 0.0 || !(fabs(c) < INFINITY)) run = false;      // tryStep threw: this step length is out
+                    if (q.bc[m3s][1] != 0.0 || !(fabs(c) < INFINITY)) run = false;      // tryStep threw: this step length is out
                     ctry += c;
                 }
                 dt_behind = dtn;
-                if (!terminal && do_chain) {
+                if (!terminal && do_chain) {     // (the chain wave's own: nobody else reads the nominal state)
+                    UNROLL_RBD for (int k = 0; k < 3; ++k) { const int i = l + kFwdLanes * k; if (i < kNX) q.xs[i] = nxs[k]; }
                     if (per_node) stage_reg(t + 1);
-                    for (int i = l; i < kNX; i += kFwdLanes) q.x[i] = q.xn[i];
-                    UNROLL_RBD for (int k = 0; k < 3; ++k) {
-                        const int i = l + kFwdLanes * k;
-                        if (i <= kNodeTaskDoubles) q.tk[p ^ 1][i] = ntk[k];
-                        if (i < kNX) q.xs[i] = nxs[k];
-                    }
                 }
             }
-            fwd_sync<NW>();
+            // ONE barrier per node: what the next node reads -- its state (written by the Euler step), its task block -- went into the
+            // other slots before the barrier above, and what this node's end reads (the cost terms) sits in slots nobody writes
+            // during the next node.  Only the per-node regularisation reference has a single copy.
+            if (per_node) fwd_sync<NW>();
             FSTAMP(4)
         }
         bool pass = false;               // the trial ran to the end and passes SolverDDP's acceptance test
