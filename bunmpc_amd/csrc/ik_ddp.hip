@@ -1324,7 +1324,7 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
     int win = 0;                        // trial slot holding the accepted trajectory
     double alpha = 1.0, cost_try = 0.0;
 #ifdef BWD_PROFILE
-    long long fwork = 0, fwait = 0, fph[5] = {0, 0, 0, 0, 0}, fpt = 0;
+    long long fwork = 0, fwait = 0, fph[5] = {0, 0, 0, 0, 0}, fpt = 0, fsum = 0;
 #define FSTAMP(k) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long now_ = __builtin_readcyclecounter(); fph[k] += now_ - fpt; fpt = now_; }
 #else
 #define FSTAMP(k)
@@ -1464,6 +1464,9 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
             FSTAMP(3)
             if (NW == 1) fwd_sync<NW>();
             // phase 5: the parts added up: CoM, centroidal momentum, their residual costs (without the state / control terms)
+#ifdef BWD_PROFILE
+            const long long fsum0 = __builtin_readcyclecounter();
+#endif
             if (run && do_sum && l == 0 && ts >= 0 && ts <= T) {
                 NodeTasks tk{q.tk[m3s]};         // (node ts's task block: this node's, or with kSplit the one before)
                 double M = 0.0, h1[3] = {0, 0, 0}, hO[6] = {0, 0, 0, 0, 0, 0}, fx[kFrameSlots][3];
@@ -1504,6 +1507,9 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
                 }
                 q.bc[m3s][0] = c;
             }
+#ifdef BWD_PROFILE
+            if (do_sum) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); fsum += __builtin_readcyclecounter() - fsum0; }
+#endif
             if (run && do_chain && !terminal) {      // the next node's task block, requested at the top of this node
                 UNROLL_RBD for (int k = 0; k < 3; ++k) { const int i = l + kFwdLanes * k; if (i <= kNodeTaskDoubles) q.tk[m3n][i] = ntk[k]; }
             }
@@ -1576,6 +1582,7 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
 #ifdef BWD_PROFILE
     if (pvalid && lane == 0) { ws[L.Qu + 8 + 2 * wave] = (double)fwork; ws[L.Qu + 9 + 2 * wave] = (double)fwait; }   // tools/bwd_profile.py
     if (pvalid && lane == 0 && wave == 0) { for (int k = 0; k < 5; ++k) ws[L.Qu + 16 + k] = (double)fph[k]; }
+    if (pvalid && lane == 0 && do_sum && wave != 0) ws[L.Qu + 22] = (double)fsum;      // the sum of the parts, on its wave
 #endif
     if (!FUSED && (!owner || !do_chain)) return;
     if (owner && do_chain) {

@@ -26,5 +26,6 @@ for B in ((1, 4096) if robot == "solo12" else (1, 1024)):
     print("B", B, "forward (last call) cycles to the node barrier / incl. barrier, summed over nodes and rounds: chain %d / %d, legs %d / %d, reg %d / %d" % tuple(fw))
     ph = ws[:, oq + 16:oq + 21].mean(0)
     print("B", B, "forward chain wave, cycles summed over nodes and rounds: dx/residual %d, (legs on one-wave builds) %d, feedback %d, Euler %d, barriers + bookkeeping %d" % tuple(ph))
+    print("B", B, "forward, the sum of a node's parts on its wave, cycles summed over nodes and rounds: %d" % ws[:, oq + 22].mean())
     print("B", B, "calcdiff node 0 cycles: stage %d, walk (|| fetch of the ik_state_kernel terms) %d, totals+columns %d, assembly %d" % tuple(cd))
     print("B", B, "cycles/node:", " ".join("%s %d" % (n, v) for n, v in zip(names, c.mean(0))), "| sum", round(c.mean(0).sum()))
