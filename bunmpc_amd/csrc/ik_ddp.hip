@@ -1196,7 +1196,7 @@ static_assert(kTrySlots >= 3 * kFwdSub - 2, "one trial slot per step length in t
 // Every vector a lane reads as a whole is 16-byte aligned and padded to the length of the batch reader that fetches it
 // (lds_batch.h): read element by element, each LDS read waits out its own latency in front of its first use.
 struct alignas(16) FwdSub {
-    double dx[kNDX], u[22], x[2][40]; double part[2][kLegs + 1][10 + 3 * kFrameSlots]; double bc[3][4];      // x, part: [node parity]; bc: [node mod 3]
+    double dx[kNDX], u[22], x[2][40]; double part[2][kLegs + 1][10 + 3 * kFrameSlots]; double bc[3][4], ft[kFrameSlots];      // x, part: [node parity]; bc: [node mod 3]; ft: the frame terms of the node being summed
     // copies of what every node reads from HBM: per problem (regularisation reference and weights), per node (task block,
     // dt, the nominal state the feedback is taken around) -- the per-node ones are fetched one node ahead
     double xreg[40], sw[kNDX], cw[22], tk[3][kNodeTaskDoubles + 3], xs[40];     // tk: [node mod 3]
@@ -1467,26 +1467,35 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
 #ifdef BWD_PROFILE
             const long long fsum0 = __builtin_readcyclecounter();
 #endif
-            if (run && do_sum && l == 0 && ts >= 0 && ts <= T) {
+            // phase 5: the parts added up.  Lanes 1..4 first, one frame each (its position from the five parts, its residual cost,
+            // its squared residual left in LDS); then lane 0: total mass, first moment, momentum -> CoM and centroidal momentum residual costs, and the
+            // node's residual cost in the order SolverDDP adds it (momentum, CoM, frames 0..3).  One lane doing all of it was the
+            // longest single-lane stretch of the robot-walk wave.
+            constexpr int kPw = 10 + 3 * kFrameSlots;      // 22 doubles per part
+            static_assert(kPw == 22 && kLegs + 1 == 5, "the batched part readers are written for five records of 22 doubles");
+            const bool sum_now = run && do_sum && ts >= 0 && ts <= T;
+            if (sum_now && l >= 1 && l <= kFrameSlots) {
                 NodeTasks tk{q.tk[m3s]};         // (node ts's task block: this node's, or with kSplit the one before)
-                double M = 0.0, h1[3] = {0, 0, 0}, hO[6] = {0, 0, 0, 0, 0, 0}, fx[kFrameSlots][3];
-                UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) fx[f][0] = fx[f][1] = fx[f][2] = 0.0;
-                constexpr int kPw = 10 + 3 * kFrameSlots;      // 22 doubles per part: five parts = 44 + 44 + 22
-                double2_t pa0[22], pa1[22], pa2[11];
-                lds_read_b128x22(lds_offset(&q.part[ps_][0][0]), pa0);
-                lds_read_b128x22(lds_offset(&q.part[ps_][2][0]), pa1);
-                lds_read_b128x11(lds_offset(&q.part[ps_][4][0]), pa2);
-                auto part_at = [&](int pa, int k) -> double {      // compile-time indices after unrolling
-                    const int e = (pa % 2) * kPw + k;
-                    const double2_t v2 = pa < 2 ? pa0[e >> 1] : pa < 4 ? pa1[e >> 1] : pa2[e >> 1];
-                    return (e & 1) ? v2.y : v2.x;
-                };
+                const int f = l - 1;
+                const double w = tk.frame_w(f);
+                double v[15], fx[3] = {0.0, 0.0, 0.0};
+                lds_read_parts_triple(lds_offset(&q.part[ps_][0][10 + 3 * f]), v);
+                UNROLL_RBD for (int pa = 0; pa <= kLegs; ++pa)
+                    UNROLL_RBD for (int c = 0; c < 3; ++c) fx[c] += v[3 * pa + c];
+                double acc = 0.0;
+                UNROLL_RBD for (int k = 0; k < 3; ++k) { const double r = w != 0.0 ? fx[k] - tk.frame_ref(f)[k] : 0.0; acc += r * r; }
+                q.ft[f] = acc;
+            }
+            if (sum_now && l == 0) {
+                NodeTasks tk{q.tk[m3s]};
+                double M = 0.0, h1[3] = {0, 0, 0}, hO[6] = {0, 0, 0, 0, 0, 0};
+                double2_t hd[25];
+                lds_read_parts_head(lds_offset(&q.part[ps_][0][0]), hd);
+                auto part_at = [&](int pa, int k) -> double { return (k & 1) ? hd[5 * pa + (k >> 1)].y : hd[5 * pa + (k >> 1)].x; };
                 UNROLL_RBD for (int pa = 0; pa <= kLegs; ++pa) {
                     M += part_at(pa, 0);
                     UNROLL_RBD for (int c = 0; c < 3; ++c) h1[c] += part_at(pa, 1 + c);
                     UNROLL_RBD for (int c = 0; c < 6; ++c) hO[c] += part_at(pa, 4 + c);
-                    UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
-                        UNROLL_RBD for (int c = 0; c < 3; ++c) fx[f][c] += part_at(pa, 10 + 3 * f + c);
                 }
                 double com[3], t3[3], c = 0.0, acc = 0.0;
                 UNROLL_RBD for (int k = 0; k < 3; ++k) com[k] = h1[k] / M;
@@ -1499,12 +1508,7 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
                 acc = 0.0;
                 UNROLL_RBD for (int k = 0; k < 3; ++k) { const double r = com[k] - tk.com_ref()[k]; acc += r * r; }
                 c += tk.com_w() * 0.5 * acc;
-                UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) {
-                    const double w = tk.frame_w(f);
-                    acc = 0.0;
-                    UNROLL_RBD for (int k = 0; k < 3; ++k) { const double r = w != 0.0 ? fx[f][k] - tk.frame_ref(f)[k] : 0.0; acc += r * r; }
-                    c += w * 0.5 * acc;
-                }
+                UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f) c += tk.frame_w(f) * 0.5 * q.ft[f];      // (q.ft: written above by this wave -- LDS keeps a wave's order)
                 q.bc[m3s][0] = c;
             }
 #ifdef BWD_PROFILE

@@ -34,6 +34,18 @@ __device__ __forceinline__ void lds_read_b128x11(unsigned addr, double2_t (&o)[1
                  : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10])
                  : "v"(addr) : "memory");
 }
+// the first ten doubles of five records of 22 doubles (the line search's part sums: mass, first moment, momentum): [5 pa + j] = doubles 2j, 2j + 1 of record pa
+__device__ __forceinline__ void lds_read_parts_head(unsigned addr, double2_t (&o)[25]) {
+    asm volatile("ds_read_b128 %0, %25 offset:0\n\tds_read_b128 %1, %25 offset:16\n\tds_read_b128 %2, %25 offset:32\n\tds_read_b128 %3, %25 offset:48\n\tds_read_b128 %4, %25 offset:64\n\tds_read_b128 %5, %25 offset:176\n\tds_read_b128 %6, %25 offset:192\n\tds_read_b128 %7, %25 offset:208\n\tds_read_b128 %8, %25 offset:224\n\tds_read_b128 %9, %25 offset:240\n\tds_read_b128 %10, %25 offset:352\n\tds_read_b128 %11, %25 offset:368\n\tds_read_b128 %12, %25 offset:384\n\tds_read_b128 %13, %25 offset:400\n\tds_read_b128 %14, %25 offset:416\n\tds_read_b128 %15, %25 offset:528\n\tds_read_b128 %16, %25 offset:544\n\tds_read_b128 %17, %25 offset:560\n\tds_read_b128 %18, %25 offset:576\n\tds_read_b128 %19, %25 offset:592\n\tds_read_b128 %20, %25 offset:704\n\tds_read_b128 %21, %25 offset:720\n\tds_read_b128 %22, %25 offset:736\n\tds_read_b128 %23, %25 offset:752\n\tds_read_b128 %24, %25 offset:768\n\t" "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15]), "=&v"(o[16]), "=&v"(o[17]), "=&v"(o[18]), "=&v"(o[19]), "=&v"(o[20]), "=&v"(o[21]), "=&v"(o[22]), "=&v"(o[23]), "=&v"(o[24])
+                 : "v"(addr) : "memory");
+}
+// three consecutive doubles of each of five records of 22 doubles, from the address of the first record's triple: [3 pa + c]
+__device__ __forceinline__ void lds_read_parts_triple(unsigned addr, double (&o)[15]) {
+    asm volatile("ds_read_b64 %0, %15 offset:0\n\tds_read_b64 %1, %15 offset:8\n\tds_read_b64 %2, %15 offset:16\n\tds_read_b64 %3, %15 offset:176\n\tds_read_b64 %4, %15 offset:184\n\tds_read_b64 %5, %15 offset:192\n\tds_read_b64 %6, %15 offset:352\n\tds_read_b64 %7, %15 offset:360\n\tds_read_b64 %8, %15 offset:368\n\tds_read_b64 %9, %15 offset:528\n\tds_read_b64 %10, %15 offset:536\n\tds_read_b64 %11, %15 offset:544\n\tds_read_b64 %12, %15 offset:704\n\tds_read_b64 %13, %15 offset:712\n\tds_read_b64 %14, %15 offset:720\n\t" "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14])
+                 : "v"(addr) : "memory");
+}
 // 18 x 16 bytes (36 doubles) from a 16-byte aligned address
 __device__ __forceinline__ void lds_read_b128x18(unsigned addr, double2_t (&o)[18]) {
     asm volatile("ds_read_b128 %0, %18 offset:0\n\tds_read_b128 %1, %18 offset:16\n\tds_read_b128 %2, %18 offset:32\n\tds_read_b128 %3, %18 offset:48\n\tds_read_b128 %4, %18 offset:64\n\tds_read_b128 %5, %18 offset:80\n\tds_read_b128 %6, %18 offset:96\n\tds_read_b128 %7, %18 offset:112\n\tds_read_b128 %8, %18 offset:128\n\tds_read_b128 %9, %18 offset:144\n\tds_read_b128 %10, %18 offset:160\n\tds_read_b128 %11, %18 offset:176\n\tds_read_b128 %12, %18 offset:192\n\tds_read_b128 %13, %18 offset:208\n\tds_read_b128 %14, %18 offset:224\n\tds_read_b128 %15, %18 offset:240\n\tds_read_b128 %16, %18 offset:256\n\tds_read_b128 %17, %18 offset:272\n\t" "s_waitcnt lgkmcnt(0)"
