@@ -1226,12 +1226,14 @@ struct ForwardLds { RobotModelDev m; FwdSub sub[kFwdSub]; double vote[kFwdSub], 
 //      passing one is the same decision -- it trades idle SIMDs for a 4x shorter serial chain when few problems
 //      are still iterating.
 //
-// NW > 1 (used with the speculative mapping): wave 1 takes the leg walks of every node and their sum, wave 2 the state
+// NW > 1 (used with the speculative mapping): wave 1 takes the leg walks of every node (with NW = 2 also the sum of their
+// parts; from three waves on that sum runs one node behind on wave 2 / 3, see forward_roles), wave 2 the state
 // regularisation residual (an SE(3) difference, as long as a leg walk; with NW = 2 it stays on wave 0, where it is the
 // SAME code as the chain's dx = xs (-) x with other operands and lane 5 runs it in the instruction stream lane 0 needs
-// anyway), while wave 0 runs the chain x -> dx -> u -> Euler step -> next x; they meet once per node.  Different code
-// cannot overlap inside a wave, but it can across the waves of a workgroup.  Two waves while the problems still cover
-// the chip (<= 1024 active), three once a third of the SIMDs would be idle anyway.
+// anyway), while wave 0 runs the chain x -> dx -> u -> Euler step -> next x; they meet ONCE per node (one barrier: what the
+// next node reads is written into rotating LDS slots before it).  Different code cannot overlap inside a wave, but it can
+// across the waves of a workgroup.  Two waves while the problems still cover the chip (<= 1024 active), three once a third
+// of the SIMDs would be idle anyway.
 // Barrier of the forward pass' workgroup.  Its waves exchange through LDS only (the trial trajectories they write to the
 // workspace are read back after the kernel, or by the same wave), so the barrier needs the LDS operations complete, not the
 // global ones: __syncthreads() would also drain the rows of K and the task blocks that are fetched one node ahead, five times
