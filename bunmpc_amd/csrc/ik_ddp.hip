@@ -229,6 +229,9 @@ struct alignas(16) CalcLds { CalcNode nd[kCalcNodes]; RobotModelDev m; };
 
 // State regularisation residual (+ its Jlog6 block) and the Euler step (+ its Jintegrate blocks, written to the workspace)
 // of node tw: the scalar chain of the derivative pass.  Returns the node's state + control cost.
+// PART: 0 all of it; 1 the state residual with its Jlog6 block and the two costs; 2 the Euler step with its Jintegrate blocks (the
+// two halves of ik_state_kernel: independent chains of about the same length, on different waves there)
+template <int PART>
 __device__ __forceinline__ double node_state_terms(const IkBatchArgs &a, long b, int tw, double *ws, const IkLayout &L, const double *x,
                                                    const double *u, const double *state_w0, const double *ctrl_w0, const double *x_reg0,
                                                    const NodeTasks &tkw, double *rs, double *Jl) {
@@ -237,19 +240,23 @@ __device__ __forceinline__ double node_state_terms(const IkBatchArgs &a, long b,
     const double wst = tkw.state_w(), wu = tkw.ctrl_w();
     const double *state_w = state_w0 + a.sn_state_w * tw, *ctrl_w = ctrl_w0 + a.sn_ctrl_w * tw;
     double cost = 0.0;
-    if (wst != 0.0) {
-        state_diff<true>(x_reg0 + a.sn_x_reg * tw, x, rs, Jl);
-        double acc = 0.0;
-        UNROLL_RBD for (int i = 0; i < kNDX; ++i) acc += state_w[i] * rs[i] * rs[i];
-        cost += wst * 0.5 * acc;
-    } else {
-        UNROLL_RBD for (int i = 0; i < kNDX; ++i) rs[i] = 0.0;
-        UNROLL_RBD for (int i = 0; i < 36; ++i) Jl[i] = (i % 7 == 0) ? 1.0 : 0.0;
+    if (PART != 2) {
+        if (wst != 0.0) {
+            state_diff<true>(x_reg0 + a.sn_x_reg * tw, x, rs, Jl);
+            double acc = 0.0;
+            UNROLL_RBD for (int i = 0; i < kNDX; ++i) acc += state_w[i] * rs[i] * rs[i];
+            cost += wst * 0.5 * acc;
+        } else {
+            UNROLL_RBD for (int i = 0; i < kNDX; ++i) rs[i] = 0.0;
+            UNROLL_RBD for (int i = 0; i < 36; ++i) Jl[i] = (i % 7 == 0) ? 1.0 : 0.0;
+        }
+        if (!terminal_w) {
+            double acc = 0.0;
+            UNROLL_RBD for (int i = 0; i < kNV; ++i) acc += ctrl_w[i] * u[i] * u[i];
+            cost += wu * 0.5 * acc;
+        }
     }
-    if (!terminal_w) {
-        double acc = 0.0;
-        UNROLL_RBD for (int i = 0; i < kNV; ++i) acc += ctrl_w[i] * u[i] * u[i];
-        cost += wu * 0.5 * acc;
+    if (PART != 1 && !terminal_w) {
         double xn[kNX], A6[36], B6[36];
         euler_step<true>(x, u, dtw, xn, A6, B6);
         UNROLL_RBD for (int i = 0; i < kNX; ++i) ws[L.xnext + (long)tw * kNX + i] = xn[i];
@@ -259,17 +266,20 @@ __device__ __forceinline__ double node_state_terms(const IkBatchArgs &a, long b,
 }
 
 // The scalar chain of node tw of problem b (ik_state_kernel's lane; a lane of the fused kernel's first producer step)
+template <int PART>
 __device__ __forceinline__ void state_node(const IkBatchArgs &a, long b, int tw, double *ws, const IkLayout &L) {
     const int nn = a.T + 1;
     double x[kNX], u[kNV], rs[kNDX], Jl[36];
     UNROLL_RBD for (int i = 0; i < kNX; ++i) x[i] = ws[L.xs + (long)tw * kNX + i];
     UNROLL_RBD for (int i = 0; i < kNV; ++i) u[i] = tw == a.T ? 0.0 : ws[L.us + (long)tw * kNV + i];
     NodeTasks tkw{a.tasks + (b * nn + tw) * kNodeTaskDoubles};
-    const double cost = node_state_terms(a, b, tw, ws, L, x, u, batch_ptr(a.state_w, a.s_state_w, b), batch_ptr(a.ctrl_w, a.s_ctrl_w, b),
-                                         a.x_reg + b * a.s_x_reg, tkw, rs, Jl);
-    UNROLL_RBD for (int i = 0; i < kNDX; ++i) ws[L.nrs + (long)tw * kNDX + i] = rs[i];
-    UNROLL_RBD for (int i = 0; i < 6; ++i) UNROLL_RBD for (int k = 0; k < 6; ++k) ws[L.njl + (long)tw * 36 + 6 * i + k] = Jl[6 * k + i];
-    ws[L.ncs + tw] = cost;
+    const double cost = node_state_terms<PART>(a, b, tw, ws, L, x, u, batch_ptr(a.state_w, a.s_state_w, b), batch_ptr(a.ctrl_w, a.s_ctrl_w, b),
+                                               a.x_reg + b * a.s_x_reg, tkw, rs, Jl);
+    if (PART != 2) {
+        UNROLL_RBD for (int i = 0; i < kNDX; ++i) ws[L.nrs + (long)tw * kNDX + i] = rs[i];
+        UNROLL_RBD for (int i = 0; i < 6; ++i) UNROLL_RBD for (int k = 0; k < 6; ++k) ws[L.njl + (long)tw * 36 + 6 * i + k] = Jl[6 * k + i];
+        ws[L.ncs + tw] = cost;
+    }
 }
 
 // ... for all nodes of all problems, ONE LANE PER NODE, launched before ik_calcdiff_kernel.  Inside that kernel (where it used
@@ -279,15 +289,20 @@ __device__ __forceinline__ void state_node(const IkBatchArgs &a, long b, int tw,
 // on its batch (the few microseconds of an extra launch per tail iteration are the price).
 __global__ __launch_bounds__(64) void ik_state_kernel(const IkBatchArgs a) {
     const int nn = a.T + 1;
-    const long idx = (long)blockIdx.x * 64 + threadIdx.x;
-    if (idx == 0 && a.count) { a.count[(a.iter + 1) & 1] = 0; a.wcount[(a.iter + 1) & 1] = 0; a.near[(a.iter + 1) & 1] = 0; }     // the lists this iteration's forward pass will fill
+    // even workgroups: the state residual, its Jlog6 block, the costs; odd workgroups: the Euler step and its Jintegrate blocks -- two
+    // independent chains of a node, each about half of the lane's work.  The kernel is latency-bound in every regime (one wave per
+    // SIMD at 434 registers, never more waves than SIMDs): half the chain is half the time.
+    const long idx = (long)(blockIdx.x >> 1) * 64 + threadIdx.x;
+    const bool second = (blockIdx.x & 1) != 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.count) { a.count[(a.iter + 1) & 1] = 0; a.wcount[(a.iter + 1) & 1] = 0; a.near[(a.iter + 1) & 1] = 0; }     // the lists this iteration's forward pass will fill
     const long b = slot_problem(a, idx / nn);
     const int tw = (int)(idx % nn);
     if (b < 0) return;
     const IkLayout L = IkLayout::make(a.T);
     double *ws = a.ws + b * L.total;
     if (ws[L.scal + S_DONE] != 0.0 || ws[L.scal + S_RECALC] == 0.0) return;
-    state_node(a, b, tw, ws, L);
+    if (second) state_node<2>(a, b, tw, ws, L);
+    else state_node<1>(a, b, tw, ws, L);
 }
 
 // ---- the pieces of the derivative pass of a node, shared by ik_calcdiff_kernel (two waves for two nodes) and the fused
@@ -1731,7 +1746,7 @@ __device__ __forceinline__ void producer_wave(const IkBatchArgs &a, long b, Fuse
         if (p == 0) { if (lane <= T) ctl.ready[lane] = stamp; if (lane == 0) ctl.state_ready = stamp; }
     } else {
         if (p == 1) {
-            if (lane <= T) state_node(a, b, lane, ws, L);
+            if (lane <= T) state_node<0>(a, b, lane, ws, L);
             stores_done();
             if (lane == 0) ctl.state_ready = stamp;
             if (tick_over()) return;
@@ -2028,7 +2043,7 @@ hipError_t ik_launch_init(const IkBatchArgs &a, hipStream_t st) {
 static long launch_problems(const IkBatchArgs &a) { return a.list ? (a.n_launch < a.B ? a.n_launch : a.B) : a.B; }
 hipError_t ik_launch_state(const IkBatchArgs &a, hipStream_t st) {
     const long n = launch_problems(a) * (a.T + 1);
-    hipLaunchKernelGGL(ik_state_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(ik_state_kernel, dim3(2u * (unsigned)((n + 63) / 64)), dim3(64), 0, st, a);      // two workgroups per 64 nodes
     return hipGetLastError();
 }
 int g_calcdiff_one_wave_above = 1024;     // node pairs per launch above which one wave takes a pair (the two-wave kernel has 1024 pairs resident on an MI355X)
