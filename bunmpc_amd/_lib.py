@@ -88,6 +88,7 @@ _SIGS = {
     "bmpc_batch_struct_size": (_I, []),
     "bmpc_set_latency_mapping_max_batch": (_I, [_I]),
     "bmpc_set_exact_step_decisions": (_I, [_I]),
+    "bmpc_biconvex_fp32_scratch_bytes": (_I, []),
     "bmpc_last_error": (C.c_char_p, []),
     "bmpc_device_count": (_I, [_P]),
     "bmpc_set_device": (_I, [_I]),

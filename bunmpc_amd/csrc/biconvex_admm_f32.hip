@@ -31,4 +31,17 @@ hipError_t launch_biconvex_admm_f32(const BatchArgs &a, int lpp, unsigned grid, 
     return hipGetLastError();
 }
 
+// private-segment (scratch) bytes per lane of the fp32 instantiations, the largest of the three: 0 is the point of this file
+int biconvex_admm_f32_scratch_bytes() {
+    size_t worst = 0;
+    hipFuncAttributes at;
+    if (hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&biconvex_admm_kernel_f32<16, 4>)) != hipSuccess) return -1;
+    worst = at.localSizeBytes > worst ? at.localSizeBytes : worst;
+    if (hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&biconvex_admm_kernel_f32<32, 4>)) != hipSuccess) return -1;
+    worst = at.localSizeBytes > worst ? at.localSizeBytes : worst;
+    if (hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&biconvex_admm_kernel_f32<64, 4>)) != hipSuccess) return -1;
+    worst = at.localSizeBytes > worst ? at.localSizeBytes : worst;
+    return (int)worst;
+}
+
 }  // namespace bunmpc

@@ -68,6 +68,8 @@ int set_exact_step_decisions(int on);                // ... takes every step dec
 // and the LDS bytes it has worked out
 hipError_t launch_biconvex_admm_f32(const BatchArgs &a, int lpp, unsigned grid, size_t lds, hipStream_t stream);
 
+int biconvex_admm_f32_scratch_bytes();    // private-segment bytes per lane of the fp32 kernels (hipFuncGetAttributes), -1 on error
+
 // Lane-exchange self test (DPP shifts and segment sums used by the kernel).
 // out must hold 6*64 doubles.
 hipError_t launch_lane_selftest(const double *in, double *out, hipStream_t stream);

@@ -142,6 +142,7 @@ int bmpc_abi_version(void) { return 1; }
 int bmpc_batch_struct_size(void) { return (int)sizeof(bmpc_batch_t); }
 int bmpc_set_latency_mapping_max_batch(int max_batch) { return bunmpc::set_latency_mapping_max_batch(max_batch); }
 int bmpc_set_exact_step_decisions(int on) { return bunmpc::set_exact_step_decisions(on); }
+int bmpc_biconvex_fp32_scratch_bytes(void) { return bunmpc::biconvex_admm_f32_scratch_bytes(); }
 const char *bmpc_last_error(void) { return g_err.c_str(); }
 
 int bmpc_device_count(int *count) {

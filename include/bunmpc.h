@@ -154,6 +154,10 @@ int bmpc_set_latency_mapping_max_batch(int max_batch);
  * expression otherwise.  on = 1: always from the fp64 sums (a test switch: results must be bit-identical either way).
  * Returns the old value. */
 int bmpc_set_exact_step_decisions(int on);
+/* Scratch (private-segment) bytes per lane of the fp32 kernels as the loaded code object reports them, -1 on error.  0 is what
+ * the build is set up for (bunmpc_amd/build.py: their translation unit is compiled without the SLP vectoriser); a compiler that
+ * spills again shows up here, and in 4x the HBM traffic. */
+int bmpc_biconvex_fp32_scratch_bytes(void);
 /* symbol-name prefix of the kernel that serves (n_col, raw), for profiles */
 const char *bmpc_biconvex_kernel_name(int n_col, int raw);
 /* which kernel the calling host thread's latest batch solve was dispatched to: "biconvex_latency_kernel" (one problem per wave),
