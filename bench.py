@@ -92,13 +92,9 @@ def cpu_baseline(config, H_iters, sample, maxit):
     oracle_c.solve_batch(b, num_iters=H_iters, maxit=maxit, nthreads=cores, fast=True)
     dt_fast = time.perf_counter() - t2
     return {"value": sample / dt, "unit": "solves/s", "cores": cores, "kind": "port",
-            "sample": "%d problems of the same workload, one solve per OpenMP thread over %d threads, "
-                      "strict restatement of the reference formulation (explicit sparse Hessian); "
-                      "not the reference binary (needs Eigen, absent)" % (sample, cores),
+            "sample": "%d problems of the workload, %d OpenMP threads, strict port (explicit sparse Hessian)" % (sample, cores),
             "single_core_ms_per_solve": lat * 1e3,
-            "matrix_free_variant": {"value": sample / dt_fast, "unit": "solves/s", "cores": cores,
-                                    "note": "same algorithm written matrix-free for the CPU (oracle/biconvex_fast.c); "
-                                            "the reference itself is the explicit-Hessian formulation above"}}
+            "matrix_free_variant": {"value": sample / dt_fast, "unit": "solves/s", "cores": cores}}
 
 
 def kinodyn_cpu_baseline(model, wb, admm_iters, maxit, sample):
@@ -122,9 +118,7 @@ def kinodyn_cpu_baseline(model, wb, admm_iters, maxit, sample):
     t_dyn, t_ik, k = run(sub, cores)
     l_dyn, l_ik, _ = run(sub.take(np.arange(min(2, n))), 1)
     return {"value": n / (t_dyn + t_ik), "unit": "KinoDynMP solves/s", "cores": cores, "kind": "port",
-            "sample": "%d problems of the same workload, one solve per OpenMP thread over %d threads: strict centroidal restatement "
-                      "(oracle/biconvex_oracle.c) + compiled IK-DDP twin (oracle/ik_ddp_oracle.c); not the reference binary "
-                      "(needs Eigen / pinocchio / crocoddyl, absent)" % (n, cores),
+            "sample": "%d problems of the workload, %d OpenMP threads, strict ADMM port + compiled IK-DDP twin" % (n, cores),
             "dyn_seconds": t_dyn, "ik_seconds": t_ik, "single_core_ms_per_solve": (l_dyn + l_ik) / min(2, n) * 1e3,
             "ddp_iters_mean": float(k["iters"].mean()), "ddp_not_converged": int((k["status"] != 0).sum())}
 
@@ -152,9 +146,7 @@ def p50_latency(config, num_iters, reps=200, warm=20):
         mp.optimize(b.x_init[0], num_iters)
         ts.append(time.perf_counter() - t0)
     ts = np.array(ts[warm:]) * 1e3
-    return {"p50_ms": float(np.median(ts)), "p90_ms": float(np.quantile(ts, 0.9)), "reps": reps, "warmups": warm,
-            "what": "BiconvexMP.optimize(x_init, %d) on one problem through the drop-in class: H2D of the inputs, one launch, "
-                    "D2H of X / F / P" % num_iters}
+    return {"p50_ms": float(np.median(ts)), "p90_ms": float(np.quantile(ts, 0.9)), "reps": reps, "warmups": warm}
 
 
 class quiet_stdout:
@@ -215,13 +207,17 @@ def _kinodyn_latency(model, q0, reps, warm):
 
 
 def pmc_traffic(workload_key):
-    """HBM bytes per launch (per solve for the KinoDyn legs) measured with rocprofv3 PMC counters for exactly this workload
-    (profiles/pmc_traffic.json), or None when no such measurement is committed."""
+    """(bytes, source): HBM bytes per launch (per batch solve for the KinoDyn legs) from the BUILDER's rocprofv3 PMC run of exactly
+    this workload, replayed from the committed profiles/pmc_traffic.json -- not measured by this process (PMC collection needs the
+    profiler around the program).  (None, reason) when no such measurement is committed."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f).get(workload_key, {}).get("traffic_bytes")
+            e = json.load(f).get(workload_key)
     except OSError:
-        return None
+        return None, "profiles/pmc_traffic.json missing"
+    if not e or e.get("traffic_bytes") is None:
+        return None, "no committed PMC run for this workload"
+    return e["traffic_bytes"], "replayed from profiles/pmc_traffic.json (builder's rocprofv3 --pmc run, %s); not measured by this process" % e.get("raw_log", "?")
 
 
 def ik_algorithmic_bytes(T, E=4):
@@ -261,6 +257,44 @@ class Dist:
 
 
 _POOLS = {}
+
+# prose that used to sit inside the legs' objects (the driver's record keeps the END of the line: numbers go there, see summary())
+NOTES = {
+    "cpu_baseline": "kind 'port': the CPU restatement of the reference algorithm under oracle/ (strict = the reference's explicit-sparse-"
+                    "Hessian formulation; matrix_free_variant = the same iteration written matrix-free), one solve per OpenMP thread; "
+                    "NOT the reference binary (it needs Eigen / pinocchio / crocoddyl, absent here)",
+    "parity": "unpinned: the reference holds no vectors for this path and cannot be built here; GPU vs independent CPU restatements with "
+              "prefix parity + per-problem CPU ensembles (tests/util.py, tests/test_parity_envelope_gpu.py, tests/test_ik_gpu.py)",
+    "go2": "synthetic Go2 legs run with mu = 10, not the reference's fixed mu = 1, at which the reference algorithm NaNs for a 15 kg robot "
+           "(tests/test_biconvex_gpu.py::test_go2_at_the_references_mu_1_diverges_as_the_oracle)",
+    "latency_batch1": "BiconvexMP.optimize(x_init, N) on one problem through the drop-in class: H2D of the inputs, one launch, D2H of X / F / P",
+    "traffic": "roofline.traffic is replayed from profiles/pmc_traffic.json (see roofline.traffic_source), never measured by this process",
+}
+
+
+def summary(out):
+    """The numbers a reader of the line's tail needs, flat and last: per KinoDyn leg ms per batch solve, speed-up over the CPU port
+    on all host cores and the dominant kernel; the batch-1 latencies."""
+    s = {"headline_ms_per_step": out.get("ms_per_step"), "headline_speedup_vs_cpu_all_cores": out.get("speedup_vs_cpu_all_cores"),
+         "headline_speedup_vs_matrix_free_cpu": out.get("speedup_vs_matrix_free_cpu"), "p50_latency_ms_batch1": out.get("p50_latency_ms_batch1")}
+    for key, short in (("kinodyn_full_solve", "kinodyn_solo12"), ("kinodyn_go2_h60", "kinodyn_go2_h60"), ("kinodyn_n100", "kinodyn_n100")):
+        leg = out.get(key)
+        if not isinstance(leg, dict):
+            continue
+        if "error" in leg:
+            s[short + "_error"] = leg["error"]
+            continue
+        dk = leg.get("roofline", {}).get("dominant_kernel", {})
+        s[short + "_ms_per_step"] = leg.get("ms_per_step")
+        s[short + "_solves_per_s"] = leg.get("value")
+        s[short + "_speedup_vs_cpu_all_cores"] = leg.get("speedup_vs_cpu_all_cores")
+        s[short + "_dominant_kernel"] = dk.get("kernel")
+        s[short + "_dominant_kernel_ms"] = dk.get("ms_per_solve_batch")
+    lk = out.get("latency_kinodyn_dropin")
+    if isinstance(lk, dict):
+        for N in (10, 100):
+            s["kd_optimize_p50_ms_N%d" % N] = lk.get("N=%d" % N, {}).get("kd_optimize_p50_ms")
+    return s
 
 
 def kinodyn_leg(D, B, admm_iters, maxit, config="solo12_h20", steps=3, warmup=1, n_streams=3, cpu_sample=0):
@@ -314,20 +348,20 @@ def kinodyn_leg(D, B, admm_iters, maxit, config="solo12_h20", steps=3, warmup=1,
     abytes = (bb.algorithmic_bytes_per_solve(H, 4) + ik_algorithmic_bytes(T)) * B
     dom = max(("ik_calcdiff_kernel", "ik_backward_kernel", "ik_forward_kernel"), key=lambda k: kern[k])
     wkey = "kinodyn %s H=%d H_ik=%d B=%d admm_iters=%d" % (config, H, T, B, admm_iters)
+    traffic, traffic_source = pmc_traffic(wkey)
     out = {"value": W * B / dt, "unit": "KinoDynMP solves/s", "workload": "%s H=%d H_ik=%d B=%d/GPU" % (config, H, T, B),
            "n_gpus": W, "batch": B, "global_batch": B * W, "ms_per_step": dt * 1e3, "steps": steps,
            "multi_stream": {"streams": n_streams, "value": W * n_streams * B / dt2, "unit": "KinoDynMP solves/s",
                             "ms_per_round_of_batches": dt2 * 1e3, "results_equal_single_stream": same},
            "ik_only_ms_per_step": dt_ik * 1e3, "ik_kernel_ms_per_solve": kern,
            "ddp_iters_mean": tele[0] / (B * W), "ddp_iters_max": int(it_max), "ddp_not_converged": int(tele[1]),
-           "admm_diverged": int(tele[2]),
-           "parity": "unpinned (crocoddyl 1.9.0 / pinocchio 2.6.9 absent): GPU vs two CPU restatements, tests/test_ik_gpu.py, "
-                     "tests/test_parity_envelope_gpu.py",
+           "admm_diverged": int(tele[2]), "admm_iters_mean": float(r["stats"][:, 0].mean()), "admm_iters_cap": admm_iters,
+           "parity": "unpinned",
            # HBM view of the whole solve (every kernel of one KinoDynMP.optimize batch): SURVEY 8d's per-solve bytes x B over the
            # wall time of a solve; `dominant_kernel` the same bytes' IK share over that kernel's summed launches.  The path is
            # latency / issue bound (EXPERIMENTS.md 9), so the fraction is tiny by construction.
            "roofline": {"bound": "hbm", "achieved": abytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": abytes / dt / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(wkey),
+                        "frac": abytes / dt / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                         "scope": "all kernels of one batch solve", "algorithmic_bytes_per_solve_batch": abytes,
                         "dominant_kernel": {"kernel": dom, "ms_per_solve_batch": kern[dom],
                                             "achieved": ik_algorithmic_bytes(T) * B / (kern[dom] * 1e-3) / 1e9 if kern[dom] > 0 else None,
@@ -432,6 +466,7 @@ def biconvex_leg(D, args):
     achieved = abytes / (kern_ms * 1e-3) / 1e9
     flops = counts[2] / W  # per launch on one GPU
     wkey = "%s H=%d B=%d admm_iters=%d fista_maxit=%d %s" % (args.config, pb.H, B, args.admm_iters, args.maxit, args.precision)
+    traffic, traffic_source = pmc_traffic(wkey)
     # the kernel the dispatch took for this batch (small batches of short horizons go to the one-problem-per-wave kernel)
     last_kernel = bb._lib.lib().bmpc_biconvex_last_kernel_name().decode()
     last_kernel = {"biconvex_admm_kernel": "biconvex_admm_kernel<double>"}.get(last_kernel, last_kernel)
@@ -446,7 +481,7 @@ def biconvex_leg(D, args):
                                % (args.config, pb.H, B, args.admm_iters, args.maxit),
                    "global_batch": B * W, "parallelism": "batch-shard x%d" % W},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(wkey),
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": last_kernel, "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_launch": abytes,
                      "valu": {"model_flops_per_launch": flops,
@@ -455,8 +490,6 @@ def biconvex_leg(D, args):
                               "frac": flops / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF}},
         "diverged": int(counts[0]), "fista_iters_per_solve": counts[1] / (B * W),
     }
-    if args.config == "go2_bound":
-        out["note"] = "synthetic Go2 runs with mu = 10, not the reference's fixed mu = 1 (the reference algorithm NaNs for a 15 kg robot at mu = 1: tests/test_oracle_cpu.py)"
     return out, pb
 
 
@@ -651,7 +684,12 @@ def main():
                                                                       cpu_sample=kd_sample("go2_h60")))
                 if world == 1:
                     out["datagen_pass"] = guarded(lambda: datagen_leg(dev, kd_batch(cfg), args.admm_iters))
+                # the reference's OWN call: kd.optimize(q, v, 100, 1) (abstract_cyclic_gen.py:663) at the headline's batch size
+                out["kinodyn_n100"] = guarded(lambda: kinodyn_leg(D, kd_batch(cfg), 100, args.maxit, cfg, steps=args.kinodyn_steps, n_streams=1,
+                                                                  cpu_sample=512 if cpu_ok else 0))
     out["rccl"] = rccl
+    out["notes"] = NOTES
+    out["summary"] = summary(out)
     sys.stdout.flush()
     os.dup2(json_fd, 1)
     os.close(json_fd)

@@ -27,7 +27,7 @@ class Batch(C.Structure):
                                            "bounds", "X_nom", "X_ter")] +
                 [(n, C.c_long) for n in ("sW_X", "sW_X_ter", "sW_F", "sbounds")] +
                 [(n, C.c_void_p) for n in ("Qx", "qx", "lbx", "ubx", "Qf", "qf", "X", "F", "P",
-                                           "L_x", "L_f", "dyn_viol", "hist", "stats")])
+                                           "L_x", "L_f", "dyn_viol", "hist", "stats", "trace")])
 
 
 class GaitParams(C.Structure):

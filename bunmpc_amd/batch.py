@@ -72,6 +72,8 @@ class DeviceBatch:
         self.stats = torch.zeros((B, NSTATS), dtype=torch.int32, device=self.device)
         self.hist = torch.full((B, max(num_iters, 1)), float("nan"), dtype=f64,
                                device=self.device) if keep_hist else None
+        # with keep_hist the solve also leaves its discrete path per ADMM iteration (bmpc_batch_t.trace; -1 where none ran)
+        self.trace = torch.full((B, max(num_iters, 1), 4), -1, dtype=torch.int32, device=self.device) if keep_hist else None
         d = _lib.Batch()
         _lib.lib().bmpc_batch_defaults(C.byref(d))
         _solver_fields(d, batch, num_iters, maxit, tol, exit_tol, beta, mu)
@@ -86,6 +88,7 @@ class DeviceBatch:
         d.L_x, d.L_f = self.L_x.data_ptr(), self.L_f.data_ptr()
         d.dyn_viol, d.stats = self.dyn_viol.data_ptr(), self.stats.data_ptr()
         d.hist = self.hist.data_ptr() if keep_hist else None
+        d.trace = self.trace.data_ptr() if keep_hist else None
         self.desc = d
 
     def set_warm_start(self, X, F, P, L_x=None, L_f=None):
@@ -114,6 +117,9 @@ class DeviceBatch:
     def solve(self):
         """Asynchronous: one launch on torch's current stream."""
         stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        if self.hist is not None:      # rows of ADMM iterations that do not run keep their NaN / -1
+            self.hist.fill_(float("nan"))
+            self.trace.fill_(-1)
         _lib.check(_lib.lib().bmpc_biconvex_solve_batch_device(C.byref(self.desc), C.c_void_p(stream)))
 
     def results(self):
@@ -123,6 +129,7 @@ class DeviceBatch:
                    dyn_viol=self.dyn_viol.cpu().numpy(), stats=self.stats.cpu().numpy().astype(np.int64))
         if self.hist is not None:
             out["hist"] = self.hist.cpu().numpy()
+            out["trace"] = self.trace.cpu().numpy().astype(np.int64)
         return out
 
 
@@ -173,9 +180,12 @@ def solve_host(batch, num_iters=10, maxit=150, tol=1e-5, exit_tol=1e-3, beta=1.5
     hist = np.full((B, max(num_iters, 1)), np.nan) if keep_hist else None
     d.X, d.F, d.P = X.ctypes.data, F.ctypes.data, P.ctypes.data
     d.L_x, d.L_f, d.dyn_viol, d.stats = Lx.ctypes.data, Lf.ctypes.data, viol.ctypes.data, stats.ctypes.data
+    trace = np.full((B, max(num_iters, 1), 4), -1, dtype=np.int32) if keep_hist else None
     d.hist = hist.ctypes.data if keep_hist else None
+    d.trace = trace.ctypes.data if keep_hist else None
     _lib.check(_lib.lib().bmpc_biconvex_solve_batch_host(C.byref(d)))
     out = dict(X=X, F=F, P=P, L_x=Lx, L_f=Lf, dyn_viol=viol, stats=stats.astype(np.int64))
     if keep_hist:
         out["hist"] = hist
+        out["trace"] = trace.astype(np.int64)
     return out

@@ -462,6 +462,10 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
                 last_viol = nrm;
                 ++n_admm;
                 if (a.hist && l0) *at(a.hist + wave0 * a.c.num_iters, 8u * (sl * (unsigned)a.c.num_iters + (unsigned)it)) = nrm;
+                if (a.trace && l0) {
+                    int *tr = a.trace + ((wave0 + sl) * a.c.num_iters + it) * 4;
+                    tr[0] = it_f; tr[1] = it_x; tr[2] = bt_f; tr[3] = bt_x;
+                }
                 if (isnan(nrm)) status = 2;                                   // biconvex.cpp:106-109
             }
             alive &= ~__ballot(isnan(nrm) || nrm < exit_tol);                 // biconvex.cpp:106-109, 111-114

@@ -47,6 +47,7 @@ struct BatchArgs {
     double *X, *F, *P, *L_x, *L_f;
     double *dyn_viol, *hist;
     int *stats;
+    int *trace;      // [B][num_iters][4] running totals {it_f, it_x, bt_f, bt_x} after every ADMM iteration, or null
 };
 
 constexpr int kStats = 6;

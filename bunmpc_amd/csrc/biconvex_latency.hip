@@ -378,6 +378,10 @@ __global__ __launch_bounds__(64) void biconvex_latency_kernel(const BatchArgs a)
             last_viol = nrm;
             ++n_admm;
             if (a.hist && lane == 0) a.hist[pb * a.c.num_iters + it] = nrm;
+            if (a.trace && lane == 0) {
+                int *tr = a.trace + (pb * a.c.num_iters + it) * 4;
+                tr[0] = it_f; tr[1] = it_x; tr[2] = bt_f; tr[3] = bt_x;
+            }
             const bool isn = __any(isnan(nrm));
             if (isn) status = 2;                                              // biconvex.cpp:106-109
             if (isn || __any(nrm < exit_tol)) alive = false;                  // biconvex.cpp:111-114

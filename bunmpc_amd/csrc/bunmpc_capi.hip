@@ -61,7 +61,7 @@ bunmpc::BatchArgs to_args(const bmpc_batch_t &d) {
     a.sW_X = d.sW_X; a.sW_X_ter = d.sW_X_ter; a.sW_F = d.sW_F; a.sbounds = d.sbounds;
     a.Qx = d.Qx; a.qx = d.qx; a.lbx = d.lbx; a.ubx = d.ubx; a.Qf = d.Qf; a.qf = d.qf;
     a.X = d.X; a.F = d.F; a.P = d.P; a.L_x = d.L_x; a.L_f = d.L_f;
-    a.dyn_viol = d.dyn_viol; a.hist = d.hist; a.stats = d.stats;
+    a.dyn_viol = d.dyn_viol; a.hist = d.hist; a.stats = d.stats; a.trace = d.trace;
     return a;
 }
 
@@ -138,7 +138,7 @@ struct bmpc_biconvex {
 
 extern "C" {
 
-int bmpc_abi_version(void) { return 1; }
+int bmpc_abi_version(void) { return 2; }
 int bmpc_batch_struct_size(void) { return (int)sizeof(bmpc_batch_t); }
 int bmpc_set_latency_mapping_max_batch(int max_batch) { return bunmpc::set_latency_mapping_max_batch(max_batch); }
 int bmpc_set_exact_step_decisions(int on) { return bunmpc::set_exact_step_decisions(on); }
@@ -631,7 +631,8 @@ int bmpc_biconvex_solve_batch_host(const bmpc_batch_t *d) {
     size_t total = 0;
     for (auto &i : ins) total += i.n;
     for (auto &o : outs) total += o.n;
-    DevBuf buf, sbuf;
+    DevBuf buf, sbuf, tbuf;
+    const size_t ntrace = B * (size_t)(d->num_iters > 0 ? d->num_iters : 1) * 4;
     HIP_TRY(buf.ensure(sizeof(double) * total));
     double *p = buf.d();
     for (auto &i : ins) {
@@ -647,10 +648,16 @@ int bmpc_biconvex_solve_batch_host(const bmpc_batch_t *d) {
         HIP_TRY(hipMemset(sbuf.p, 0, sizeof(int) * bunmpc::kStats * B));
         b.stats = static_cast<int *>(sbuf.p);
     }
+    if (d->trace) {      // rows of ADMM iterations that do not run keep the caller's values
+        HIP_TRY(tbuf.ensure(sizeof(int) * ntrace));
+        HIP_TRY(hipMemcpy(tbuf.p, d->trace, sizeof(int) * ntrace, hipMemcpyHostToDevice));
+        b.trace = static_cast<int *>(tbuf.p);
+    }
     HIP_TRY(bunmpc::launch_biconvex_admm(to_args(b), d->n_eff, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     for (auto &o : outs) HIP_TRY(hipMemcpy(o.host, *o.slot, sizeof(double) * o.n, hipMemcpyDeviceToHost));
     if (d->stats) HIP_TRY(hipMemcpy(d->stats, sbuf.p, sizeof(int) * bunmpc::kStats * B, hipMemcpyDeviceToHost));
+    if (d->trace) HIP_TRY(hipMemcpy(d->trace, tbuf.p, sizeof(int) * ntrace, hipMemcpyDeviceToHost));
     return BMPC_OK;
 }
 

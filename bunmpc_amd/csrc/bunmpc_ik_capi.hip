@@ -189,7 +189,7 @@ Sched default_sched() { return Sched{g_spec_line_search_below.load(), g_all_step
 // batch can never overwrite the counter of another batch running on a different stream; and the few entries (one per stream
 // ever used) live as long as the library, whatever threads come and go (bunmpc_amd/pipeline.py starts workers per call).
 struct ActiveWord {
-    int *host[2] = {nullptr, nullptr}, *dev[2] = {nullptr, nullptr};      // four ints each: active, index-check code, list length, express taken
+    int *host[2] = {nullptr, nullptr}, *dev[2] = {nullptr, nullptr};      // eight ints each: active, index-check code, list length, express taken, iterations (fused-direct)
     hipStream_t side = nullptr;                 // the express lane's stream (ik_fused_kernel beside the batch's own kernels)
     hipEvent_t x_go = nullptr, x_done = nullptr;
     // evs[0]: spinning waits, evs[1]: blocking waits (hipEventBlockingSync: the waiting host thread sleeps until the interrupt --
@@ -199,7 +199,7 @@ struct ActiveWord {
     int ensure() {
         if (host[0]) return BMPC_OK;
         for (int k = 0; k < 2; ++k) {
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&host[k]), 4 * sizeof(int), hipHostMallocMapped));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&host[k]), 8 * sizeof(int), hipHostMallocMapped));
             HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&dev[k]), host[k], 0));
             HIP_TRY(hipEventCreateWithFlags(&evs[0][k], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&evs[1][k], hipEventDisableTiming | hipEventBlockingSync));
@@ -264,6 +264,12 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run, const
     ActiveWord &w = *wp;
     std::lock_guard<std::mutex> hold(w.in_use);
     if (int rc = w.ensure()) return rc;
+    // Every return below (the error ones too) leaves with the side stream idle: work queued there reads xmeta / xlist, which the
+    // next batch on this stream rewrites as soon as w.in_use is free.
+    struct SideDrain {
+        hipStream_t side; bool armed = false;
+        ~SideDrain() { if (armed) (void)hipStreamSynchronize(side); }
+    } side_drain{w.side};
     hipEvent_t *ev = w.evs[g_blocking_waits.load() ? 1 : 0];
     HIP_TRY(bunmpc::ik_launch_init(a, st));
     if (sched.debug_inject == 1 && a.list) HIP_TRY(hipMemsetAsync(a.list, 0x7f, sizeof(int), st));      // tests: an entry far out of range
@@ -272,11 +278,15 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run, const
     if (a.list && a.B <= sched.fused_direct && a.maxiter > 0) {
         a.iter = 0; a.n_launch = a.B;
         HIP_TRY(bunmpc::ik_launch_fused_tail(a, st));
-        HIP_TRY(bunmpc::ik_launch_publish_active(a, 0, w.dev[0], st));
+        HIP_TRY(bunmpc::ik_launch_publish_active(a, 0, w.dev[0], st, a.B));
         HIP_TRY(hipEventRecord(ev[0], st));
         HIP_TRY(hipEventSynchronize(ev[0]));
         const volatile int *hw = static_cast<volatile int *>(w.host[0]);
-        if (iters_run) *iters_run = a.maxiter;
+        if (iters_run) *iters_run = hw[4];        // the most iterations any problem of the batch ran (one launch: there is no host loop to count)
+        if (prof) {                               // no per-kernel split exists on this path: the profile of an earlier batch must not stand
+            std::lock_guard<std::mutex> hold_p(g_profile_lock);
+            for (int k = 0; k < 5; ++k) g_last_profile[k] = 0.0;
+        }
         if (hw[1]) return index_check_failed(hw[1]);
         if (hw[0] != 0) return ik_fail(BMPC_DEVICE_ERROR, "the fused kernel left problems unsolved");
         return BMPC_OK;
@@ -308,6 +318,7 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run, const
                 HIP_TRY(bunmpc::ik_launch_select(a, express_cap, sched.debug_inject == 2, st));
                 HIP_TRY(hipEventRecord(w.x_go, st));
                 HIP_TRY(hipStreamWaitEvent(w.side, w.x_go, 0));
+                side_drain.armed = true;
                 HIP_TRY(bunmpc::ik_launch_fused_express(a, express_cap, w.side));
                 HIP_TRY(hipEventRecord(w.x_done, w.side));
                 ++express_enqueued;
@@ -361,6 +372,7 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run, const
         const volatile int *hw = static_cast<volatile int *>(w.host[0]);
         all_active = hw[0];
         if (!index_err) index_err = hw[1];
+        side_drain.armed = false;      // the look above came behind x_done: the side stream has drained
     }
     if (index_err) return index_check_failed(index_err);
     if (prof && !pev.empty()) {

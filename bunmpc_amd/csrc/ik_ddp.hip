@@ -1938,6 +1938,13 @@ __global__ __launch_bounds__(1024) void ik_select_kernel(const IkBatchArgs a, in
         bool take = k > kth;
         if (!take && k == kth) take = atomicAdd(&nk_s, 1) < remaining;
         if (take) { const int at = atomicAdd(&nx_s, 1); if (at < kExpressMax) a.xlist[at] = p; else take = false; }
+        if (take && a.wide) {
+            // a taken problem that holds a place of the wide list gives it up (-1 = an empty place): the two extra workgroups of this
+            // iteration's line search would otherwise read its trajectories and gains while the fused kernel rewrites them on
+            // the side stream.  (S_WIDENOW stays: with it cleared an extra workgroup would behave as a regular one.)
+            const int nw = a.wcount[cur] < kWideMax ? a.wcount[cur] : kWideMax;
+            for (int e = 0; e < nw; ++e) if (a.wide[cur * kWideMax + e] == p) a.wide[cur * kWideMax + e] = -1;
+        }
         if (!take) other[atomicAdd(&go_s, 1) - 1] = p;         // go_s was 1: it now counts the kept ones + 1
     }
     __syncthreads();
@@ -1995,7 +2002,13 @@ __global__ void ik_state_ops_selftest_kernel(const double *x0, const double *x1,
 
 // the active-problem counter, copied to a host-mapped word: the host reads it after its stream synchronisation
 // without a device-to-host copy operation (a 4-byte hipMemcpy into pageable memory costs ~50 us per DDP iteration)
-__global__ void ik_publish_active_kernel(const int *active, const int *err, const int *count_next, const int *xmeta, volatile int *host_word) {
+__global__ void ik_publish_active_kernel(const int *active, const int *err, const int *count_next, const int *xmeta, volatile int *host_word,
+                                         const double *ws, long ws_stride, long scal, int n_iters_of) {
+    if (n_iters_of > 0) {      // the fused-direct path (a handful of problems): the most DDP iterations any of them ran
+        int mx = 0;
+        for (int b = 0; b < n_iters_of; ++b) { const int n = (int)ws[b * ws_stride + scal + S_ITERS]; mx = n > mx ? n : mx; }
+        host_word[4] = mx;
+    }
     host_word[1] = err ? err[0] : 0;
     host_word[2] = count_next ? *count_next : -1;       // problems on the list the next iteration runs over (the express lane's are not)
     host_word[3] = xmeta ? xmeta[0] : 0;                // the express lane has taken its problems
@@ -2031,8 +2044,10 @@ hipError_t ik_launch_state_ops_selftest(const double *x0, const double *x1, cons
     hipLaunchKernelGGL(ik_state_ops_selftest_kernel, dim3((n + 63) / 64), dim3(64), 0, st, x0, x1, dx, n, dq, dr, iq, ir);
     return hipGetLastError();
 }
-hipError_t ik_launch_publish_active(const IkBatchArgs &a, int next_iter, int *host_word_dev, hipStream_t st) {
-    hipLaunchKernelGGL(ik_publish_active_kernel, dim3(1), dim3(1), 0, st, a.active, a.err, a.count ? a.count + (next_iter & 1) : nullptr, a.xmeta, host_word_dev);
+hipError_t ik_launch_publish_active(const IkBatchArgs &a, int next_iter, int *host_word_dev, hipStream_t st, int n_iters_of) {
+    const IkLayout L = IkLayout::make(a.T);
+    hipLaunchKernelGGL(ik_publish_active_kernel, dim3(1), dim3(1), 0, st, a.active, a.err, a.count ? a.count + (next_iter & 1) : nullptr, a.xmeta, host_word_dev,
+                       a.ws, L.total, L.scal, n_iters_of);
     return hipGetLastError();
 }
 hipError_t ik_launch_init(const IkBatchArgs &a, hipStream_t st) {

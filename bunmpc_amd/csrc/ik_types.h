@@ -127,7 +127,8 @@ hipError_t ik_launch_backward(const IkBatchArgs &a, hipStream_t s);
 hipError_t ik_launch_forward(const IkBatchArgs &a, hipStream_t s);
 // host_word_dev[0..3] = *active, index-check code, length of the list iteration next_iter runs over, express lane taken
 // (device alias of four host-mapped ints)
-hipError_t ik_launch_publish_active(const IkBatchArgs &a, int next_iter, int *host_word_dev, hipStream_t s);
+// n_iters_of > 0: also host word [4] = the most DDP iterations any of the first n_iters_of problems ran (fused-direct path)
+hipError_t ik_launch_publish_active(const IkBatchArgs &a, int next_iter, int *host_word_dev, hipStream_t s, int n_iters_of = 0);
 hipError_t ik_launch_select(const IkBatchArgs &a, int cap, int force, hipStream_t s);   // force: tests (take the lane whatever the batch looks like)
 hipError_t ik_launch_fused_express(const IkBatchArgs &a, int cap, hipStream_t side);
 hipError_t ik_launch_fused_tail(const IkBatchArgs &a, hipStream_t s);

@@ -11,7 +11,8 @@ from .inverse_kinematics_cpp import as_device_model
 
 
 class KinoDynDeviceBatch:
-    def __init__(self, wb, model, device="cuda", num_iters=10, maxit=150, ddp_maxiter=100, plan=None, use_active_list=True, schedule=None):
+    def __init__(self, wb, model, device="cuda", num_iters=10, maxit=150, ddp_maxiter=100, plan=None, use_active_list=True, schedule=None,
+                 keep_hist=False):
         """plan: a plan_batch.DeviceWbPlan whose tensors replace the host-built centroidal inputs and IK task blocks of
         `wb` (weights and regularisation references still come from wb).  schedule: dict of bmpc_ik_sched_t fields for this
         batch's DDP loops (0 = process default, < 0 = never), e.g. {"gains_wave_below": -1}; no effect on results"""
@@ -19,7 +20,7 @@ class KinoDynDeviceBatch:
         self.torch = torch
         self.wb = wb
         self.dm = as_device_model(model)
-        self.dyn = DeviceBatch(wb.dyn, device=device, num_iters=num_iters, maxit=maxit, plan=plan)
+        self.dyn = DeviceBatch(wb.dyn, device=device, num_iters=num_iters, maxit=maxit, plan=plan, keep_hist=keep_hist)
         self.device = self.dyn.device
         B, T = wb.dyn.B, wb.ik_T
         f64 = torch.float64
@@ -73,6 +74,9 @@ class KinoDynDeviceBatch:
     def solve(self):
         """one full batch of KinoDynMP.optimize; synchronises once per DDP iteration (active counter)"""
         stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        if self.dyn.hist is not None:      # rows of ADMM iterations that do not run keep their NaN / -1
+            self.dyn.hist.fill_(float("nan"))
+            self.dyn.trace.fill_(-1)
         _lib.check(_lib.lib().bmpc_kinodyn_solve_batch_device(C.byref(self.desc), C.c_void_p(stream)))
 
     def solve_ik_only(self):

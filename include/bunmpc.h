@@ -111,6 +111,11 @@ int bmpc_biconvex_set_robot_mass(bmpc_biconvex_t *h, double m);
  *   raw form (raw = 1): Qx, qx, lbx, ubx [B][9(H+1)], Qf [B][3EH], qf [B][3EH] or NULL
  *   X [B][9(H+1)], F [B][3EH], P [B][9(H+1)], L_x [B], L_f [B]   in: warm start, out: result
  *   dyn_viol [B] or NULL, hist [B][num_iters] or NULL, stats [B][6] or NULL
+ *   trace [B][num_iters][4] ints or NULL: running totals {F-step FISTA iterations, X-step FISTA iterations, F-step retries,
+ *       X-step retries} after every ADMM iteration that ran (rows of iterations that did not run are not written) -- with hist
+ *       the solve's discrete path per ADMM iteration, what the prefix-parity tests compare with the CPU oracle's
+ *   A caller built against an older header must zero-initialise the whole struct (bmpc_batch_defaults does) and check
+ *   bmpc_batch_struct_size() == sizeof(bmpc_batch_t).
  */
 typedef struct {
     int B, n_col, n_eff, raw;
@@ -132,6 +137,7 @@ typedef struct {
     double *X, *F, *P, *L_x, *L_f;
     double *dyn_viol, *hist;
     int *stats;
+    int *trace;       /* ABI version 2 */
 } bmpc_batch_t;
 
 /* reference defaults: rho 1e5 (biconvex.hpp:148), mu 1, beta 1.5, tol 1e-5, exit_tol 1e-3,
@@ -224,7 +230,11 @@ int bmpc_ik_last_stats(const bmpc_ik_t *h, int *iters, int *status, double *cost
 #define BMPC_IK_NODE_TASK_DOUBLES 33
 /* Scheduling thresholds of ONE batch solve (no effect on results; they replace flipping the process-wide bmpc_ik_set_* defaults
  * around a call, which raced between host threads driving different streams).  Every field: 0 = the process default,
- * < 0 = never, n > 0 = while at most n problems are still iterating. */
+ * < 0 = never, n > 0 = while at most n problems are still iterating.
+ * ABI version 2 (bmpc_abi_version): bmpc_ik_batch_t ends in this struct and active_list grew with it.  A caller MUST
+ * zero-initialise the whole bmpc_ik_batch_t (memset) before filling it -- a zero sched is "all defaults, no test switch" --,
+ * check bmpc_ik_batch_struct_size() == sizeof(bmpc_ik_batch_t), and size active_list with bmpc_ik_active_list_ints(B), never with
+ * a formula of its own (the list code writes the express lane's xlist / xmeta behind the two lists). */
 typedef struct {
     int spec_below;         /* four step lengths of a problem side by side (bmpc_ik_set_speculative_below) */
     int all_steps_below;    /* all ten step lengths at once on three workgroups (bmpc_ik_set_all_steps) */
@@ -233,7 +243,8 @@ typedef struct {
                                0 = the process default, < 0 = no express lane) */
     int debug_inject;       /* tests only: 1 = overwrite the first active-list entry with an out-of-range index right after the
                                list is initialised; the solve must then return BMPC_DEVICE_ERROR (index checks of the list code);
-                               2 = the express lane takes its problems in front of iteration 2 whatever the batch looks like */
+                               2 = the express lane takes its problems in front of iteration 2 whatever the batch looks like;
+                               any other value is ignored (as 0) */
 } bmpc_ik_sched_t;
 typedef struct {
     int B, n_col, maxiter;

@@ -168,7 +168,8 @@ static int fista_x(fast_t *w, double *x, double *L, int *retries) {
 }
 
 /* ----------------------------------------------------------------------------- ADMM (biconvex.cpp:80-120) */
-static int solve_one(fast_t *w, double *X, double *F, double *P, double *L_x, double *L_f, int num_iters, int *stats) {
+static int solve_one(fast_t *w, double *X, double *F, double *P, double *L_x, double *L_f, int num_iters, int *stats, double *hist,
+                     int *trace) {
     const int H = w->H, E = w->E, nx = 9 * (H + 1);
     int n_admm = 0, it_f = 0, it_x = 0, bt_f = 0, bt_x = 0, status = 0;
     for (int it = 0; it < num_iters; ++it) {
@@ -226,6 +227,8 @@ static int solve_one(fast_t *w, double *X, double *F, double *P, double *L_x, do
         for (int l = 0; l < 9; ++l) { const double d = X[l] - w->x_init[l]; P[9 * H + l] += d; v2 += d * d; }
         const double nrm = sqrt(v2);
         ++n_admm;
+        if (hist) hist[it] = nrm;
+        if (trace) { trace[4 * it] = it_f; trace[4 * it + 1] = it_x; trace[4 * it + 2] = bt_f; trace[4 * it + 3] = bt_x; }
         if (isnan(nrm)) { status = 2; break; }
         if (nrm < w->exit_tol) break;
     }
@@ -233,12 +236,12 @@ static int solve_one(fast_t *w, double *X, double *F, double *P, double *L_x, do
     return status;
 }
 
-int orc_fast_solve_batch(int B, int n_col, int n_eff, double m, const orc_params_t *prm,
-                         const double *cnt_plan, const double *dt, const double *x_init,
-                         const double *Qx, const double *qx, const double *Qf, const double *qf,
-                         const double *lbx, const double *ubx, int shared_cost,
-                         double *X, double *F, double *P, double *L_x, double *L_f, int num_iters,
-                         int *stats, int nthreads) {
+int orc_fast_solve_batch_traced(int B, int n_col, int n_eff, double m, const orc_params_t *prm,
+                                const double *cnt_plan, const double *dt, const double *x_init,
+                                const double *Qx, const double *qx, const double *Qf, const double *qf,
+                                const double *lbx, const double *ubx, int shared_cost,
+                                double *X, double *F, double *P, double *L_x, double *L_f, int num_iters,
+                                int *stats, int nthreads, double *hist, int *trace) {
     const int H = n_col, E = n_eff, nx = 9 * (H + 1), nf = 3 * E * H;
     if (E > MAXE) return -1;
     const int nmax = nx > nf ? nx : nf;
@@ -270,10 +273,21 @@ int orc_fast_solve_batch(int B, int n_col, int n_eff, double m, const orc_params
             w.cnt = cnt_plan + (long)b * H * E * 4; w.dt = dt + (long)b * H; w.x_init = x_init + (long)b * 9;
             w.Qx = Qx + cb * nx; w.qx = qx + (long)b * nx; w.Qf = Qf + cb * nf; w.qf = qf ? qf + cb * nf : NULL;
             w.lbx = lbx + (long)b * nx; w.ubx = ubx + (long)b * nx;
-            if (solve_one(&w, X + (long)b * nx, F + (long)b * nf, P + (long)b * nx, L_x + b, L_f + b, num_iters, stats + (long)b * ORC_NSTATS))
+            if (solve_one(&w, X + (long)b * nx, F + (long)b * nf, P + (long)b * nx, L_x + b, L_f + b, num_iters, stats + (long)b * ORC_NSTATS,
+                          hist ? hist + (long)b * num_iters : NULL, trace ? trace + (long)b * num_iters * 4 : NULL))
                 ++ndiv;
         }
         free(buf);
     }
     return ndiv;
+}
+
+int orc_fast_solve_batch(int B, int n_col, int n_eff, double m, const orc_params_t *prm,
+                         const double *cnt_plan, const double *dt, const double *x_init,
+                         const double *Qx, const double *qx, const double *Qf, const double *qf,
+                         const double *lbx, const double *ubx, int shared_cost,
+                         double *X, double *F, double *P, double *L_x, double *L_f, int num_iters,
+                         int *stats, int nthreads) {
+    return orc_fast_solve_batch_traced(B, n_col, n_eff, m, prm, cnt_plan, dt, x_init, Qx, qx, Qf, qf, lbx, ubx, shared_cost, X, F, P,
+                                       L_x, L_f, num_iters, stats, nthreads, NULL, NULL);
 }

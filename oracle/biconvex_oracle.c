@@ -396,14 +396,14 @@ void orc_default_params(orc_params_t *p) {
     p->rho = 1e5; p->beta = 1.5; p->mu = 1.0; p->tol = 1e-5; p->exit_tol = 1e-3; p->maxit = 150;
 }
 
-int orc_biconvex_solve(int n_col, int n_eff, double m, const orc_params_t *prm,
-                       const double *cnt_plan, const double *dt, const double *x_init,
-                       const double *Qx, const double *qx,
-                       const double *Qf, const double *qf,
-                       const double *lbx, const double *ubx,
-                       double *X, double *F, double *P,
-                       double *L_x, double *L_f, int num_iters,
-                       double *dyn_viol_hist, int *stats) {
+static int orc_biconvex_solve_traced(int n_col, int n_eff, double m, const orc_params_t *prm,
+                              const double *cnt_plan, const double *dt, const double *x_init,
+                              const double *Qx, const double *qx,
+                              const double *Qf, const double *qf,
+                              const double *lbx, const double *ubx,
+                              double *X, double *F, double *P,
+                              double *L_x, double *L_f, int num_iters,
+                              double *dyn_viol_hist, int *stats, int *trace) {
     const int nx = 9 * (n_col + 1), nf = 3 * n_eff * n_col;
     prob_t px, pf; /* prob_data_x holds X (uses A_f); prob_data_f holds F (uses A_x) */
     prob_init(&px, nx, nx);
@@ -435,6 +435,7 @@ int orc_biconvex_solve(int n_col, int n_eff, double m, const orc_params_t *prm,
         const double nrm = sqrt(nrm2);
         ++it_admm;
         if (dyn_viol_hist) dyn_viol_hist[i] = nrm;
+        if (trace) { trace[4 * i] = it_f; trace[4 * i + 1] = it_x; trace[4 * i + 2] = ff.n_bt; trace[4 * i + 3] = fx.n_bt; }
         if (isnan(nrm)) { status = 2; break; }   /* biconvex.cpp:106-109 */
         if (nrm < prm->exit_tol) break;          /* biconvex.cpp:111-114 */
     }
@@ -450,14 +451,26 @@ int orc_biconvex_solve(int n_col, int n_eff, double m, const orc_params_t *prm,
     return status;
 }
 
-int orc_biconvex_solve_batch(int B, int n_col, int n_eff, double m, const orc_params_t *prm,
-                             const double *cnt_plan, const double *dt, const double *x_init,
-                             const double *Qx, const double *qx,
-                             const double *Qf, const double *qf,
-                             const double *lbx, const double *ubx, int shared_cost,
-                             double *X, double *F, double *P,
-                             double *L_x, double *L_f, int num_iters,
-                             int *stats, int nthreads) {
+int orc_biconvex_solve(int n_col, int n_eff, double m, const orc_params_t *prm,
+                       const double *cnt_plan, const double *dt, const double *x_init,
+                       const double *Qx, const double *qx,
+                       const double *Qf, const double *qf,
+                       const double *lbx, const double *ubx,
+                       double *X, double *F, double *P,
+                       double *L_x, double *L_f, int num_iters,
+                       double *dyn_viol_hist, int *stats) {
+    return orc_biconvex_solve_traced(n_col, n_eff, m, prm, cnt_plan, dt, x_init, Qx, qx, Qf, qf, lbx, ubx, X, F, P, L_x, L_f,
+                                     num_iters, dyn_viol_hist, stats, NULL);
+}
+
+int orc_biconvex_solve_batch_traced(int B, int n_col, int n_eff, double m, const orc_params_t *prm,
+                                    const double *cnt_plan, const double *dt, const double *x_init,
+                                    const double *Qx, const double *qx,
+                                    const double *Qf, const double *qf,
+                                    const double *lbx, const double *ubx, int shared_cost,
+                                    double *X, double *F, double *P,
+                                    double *L_x, double *L_f, int num_iters,
+                                    int *stats, int nthreads, double *hist, int *trace) {
     const int nx = 9 * (n_col + 1), nf = 3 * n_eff * n_col;
     int ndiv = 0;
 #ifdef _OPENMP
@@ -468,15 +481,28 @@ int orc_biconvex_solve_batch(int B, int n_col, int n_eff, double m, const orc_pa
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : ndiv)
     for (int b = 0; b < B; ++b) {
         const size_t cb = shared_cost ? 0 : (size_t)b;
-        int st = orc_biconvex_solve(
+        int st = orc_biconvex_solve_traced(
             n_col, n_eff, m, prm, cnt_plan + (size_t)b * n_col * n_eff * 4, dt + (size_t)b * n_col,
             x_init + (size_t)b * 9, Qx + cb * nx, qx + (size_t)b * nx, Qf + cb * nf,
             qf ? qf + cb * nf : NULL, lbx + (size_t)b * nx, ubx + (size_t)b * nx,
             X + (size_t)b * nx, F + (size_t)b * nf, P + (size_t)b * nx, L_x + b, L_f + b,
-            num_iters, NULL, stats ? stats + (size_t)b * ORC_NSTATS : NULL);
+            num_iters, hist ? hist + (size_t)b * num_iters : NULL, stats ? stats + (size_t)b * ORC_NSTATS : NULL,
+            trace ? trace + (size_t)b * num_iters * 4 : NULL);
         ndiv += (st != 0);
     }
     return ndiv;
+}
+
+int orc_biconvex_solve_batch(int B, int n_col, int n_eff, double m, const orc_params_t *prm,
+                             const double *cnt_plan, const double *dt, const double *x_init,
+                             const double *Qx, const double *qx,
+                             const double *Qf, const double *qf,
+                             const double *lbx, const double *ubx, int shared_cost,
+                             double *X, double *F, double *P,
+                             double *L_x, double *L_f, int num_iters,
+                             int *stats, int nthreads) {
+    return orc_biconvex_solve_batch_traced(B, n_col, n_eff, m, prm, cnt_plan, dt, x_init, Qx, qx, Qf, qf, lbx, ubx, shared_cost,
+                                           X, F, P, L_x, L_f, num_iters, stats, nthreads, NULL, NULL);
 }
 
 /* biconvex.cpp:27-55 */

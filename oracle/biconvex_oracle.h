@@ -84,6 +84,27 @@ int orc_biconvex_solve_batch(int B, int n_col, int n_eff, double m, const orc_pa
                              double *L_x, double *L_f, int num_iters,
                              int *stats, int nthreads);
 
+/* ... with the solve's history: hist [B][num_iters] = ||A_f X - b_f|| after every ADMM iteration (collect_statistics,
+ * biconvex.cpp:101-104), trace [B][num_iters][4] = running totals {F-step FISTA iterations, X-step FISTA iterations, F-step
+ * retries, X-step retries} after every ADMM iteration.  Rows of iterations that did not run are left untouched.  Either may
+ * be NULL.  Used by the prefix-parity tests (tests/util.py::prefix_parity). */
+int orc_biconvex_solve_batch_traced(int B, int n_col, int n_eff, double m, const orc_params_t *prm,
+                                    const double *cnt_plan, const double *dt, const double *x_init,
+                                    const double *Qx, const double *qx,
+                                    const double *Qf, const double *qf,
+                                    const double *lbx, const double *ubx, int shared_cost,
+                                    double *X, double *F, double *P,
+                                    double *L_x, double *L_f, int num_iters,
+                                    int *stats, int nthreads, double *hist, int *trace);
+int orc_fast_solve_batch_traced(int B, int n_col, int n_eff, double m, const orc_params_t *prm,
+                                const double *cnt_plan, const double *dt, const double *x_init,
+                                const double *Qx, const double *qx,
+                                const double *Qf, const double *qf,
+                                const double *lbx, const double *ubx, int shared_cost,
+                                double *X, double *F, double *P,
+                                double *L_x, double *L_f, int num_iters,
+                                int *stats, int nthreads, double *hist, int *trace);
+
 /* Same arguments and results, matrix-free (biconvex_fast.c): the faster CPU baseline of bench.py. */
 int orc_fast_solve_batch(int B, int n_col, int n_eff, double m, const orc_params_t *prm,
                          const double *cnt_plan, const double *dt, const double *x_init,

@@ -111,9 +111,12 @@ def biconvex_solve(cnt_plan, dt, m, x_init, Qx, qx, Qf, lbx, ubx, X, F, P, L_x=2
 
 
 def solve_batch(batch, num_iters=10, maxit=150, tol=1e-5, exit_tol=1e-3, nthreads=0,
-                L_x=2.25e6, L_f=506.25, warm=None, fast=False):
+                L_x=2.25e6, L_f=506.25, warm=None, fast=False, trace=False, x_init=None):
     """Solve a bunmpc_amd.problems.Batch with the C oracle (cold start unless warm=(X,F,P)).
-    fast=True: the matrix-free variant (biconvex_fast.c) instead of the strict restatement."""
+    fast=True: the matrix-free variant (biconvex_fast.c) instead of the strict restatement.
+    trace=True: also `hist` [B][num_iters] (||A_f X - b_f|| after every ADMM iteration, NaN where none ran) and `trace`
+    [B][num_iters][4] (running totals F-iterations, X-iterations, F-retries, X-retries; -1 where none ran).
+    x_init: replaces batch.x_init (the perturbed members of tools/chaos_ensemble.py); the cold start tiles it like the batch's."""
     B, H, E = batch.B, batch.H, batch.E
     nx, nf = 9 * (H + 1), 3 * E * H
     Qx = np.empty((B, nx)); qx = np.empty((B, nx)); lbx = np.empty((B, nx)); ubx = np.empty((B, nx))
@@ -125,14 +128,20 @@ def solve_batch(batch, num_iters=10, maxit=150, tol=1e-5, exit_tol=1e-3, nthread
         Qf[b] = batch.W_F[0 if batch.W_F.shape[0] == 1 else b]
     X, F, P = batch.warm_start() if warm is None else [np.array(a, dtype=np.float64) for a in warm]
     X, F, P = _f64(X), _f64(F), _f64(P)
+    if x_init is not None and warm is None:      # KinoDynMP::set_warm_starts tiles x_init (kino_dyn.cpp:83-99)
+        X = np.ascontiguousarray(np.tile(np.asarray(x_init, np.float64), (1, H + 1)))
     Lx = np.full(B, L_x); Lf = np.full(B, L_f)
     stats = np.zeros((B, NSTATS), dtype=np.int32)
     prm = Params(batch.rho, 1.5, getattr(batch, 'mu', 1.0), tol, exit_tol, maxit)
-    cnt, dt, xi = _f64(batch.cnt_plan), _f64(batch.dt), _f64(batch.x_init)
-    fn = lib().orc_fast_solve_batch if fast else lib().orc_biconvex_solve_batch
+    cnt, dt, xi = _f64(batch.cnt_plan), _f64(batch.dt), _f64(batch.x_init if x_init is None else x_init)
+    hist = np.full((B, max(num_iters, 1)), np.nan) if trace else None
+    tr = np.full((B, max(num_iters, 1), 4), -1, dtype=np.int32) if trace else None
+    fn = lib().orc_fast_solve_batch_traced if fast else lib().orc_biconvex_solve_batch_traced
     ndiv = fn(B, H, E, C.c_double(batch.m), C.byref(prm), _p(cnt), _p(dt),
-                                          _p(xi), _p(Qx), _p(qx), _p(Qf), None, _p(lbx), _p(ubx), 0,
-                                          _p(X), _p(F), _p(P), _p(Lx), _p(Lf), num_iters, _p(stats),
-                                          nthreads)
-    return dict(X=X, F=F, P=P, L_x=Lx, L_f=Lf, stats=stats.astype(np.int64), n_diverged=ndiv,
-                Qx=Qx, qx=qx, Qf=Qf, lbx=lbx, ubx=ubx)
+              _p(xi), _p(Qx), _p(qx), _p(Qf), None, _p(lbx), _p(ubx), 0,
+              _p(X), _p(F), _p(P), _p(Lx), _p(Lf), num_iters, _p(stats), nthreads, _p(hist), _p(tr))
+    out = dict(X=X, F=F, P=P, L_x=Lx, L_f=Lf, stats=stats.astype(np.int64), n_diverged=ndiv,
+               Qx=Qx, qx=qx, Qf=Qf, lbx=lbx, ubx=ubx)
+    if trace:
+        out["hist"], out["trace"] = hist, tr.astype(np.int64)
+    return out

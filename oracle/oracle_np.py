@@ -164,7 +164,7 @@ def biconvex_solve(cnt_plan, dt, m, x_init, Qx, qx, Qf, lbx, ubx, X, F, P,
     P = np.array(P, float)
     fx = Fista(L_x, beta, mu, soc=False)
     ff = Fista(L_f, beta, mu, soc=True)
-    hist, it_f, it_x, status, n_admm = [], 0, 0, 0, 0
+    hist, trace, it_f, it_x, status, n_admm = [], [], 0, 0, 0, 0
     for _ in range(num_iters):
         A, b = build_A_x(px.x, cnt_plan, dt, m)
         pf.set_data(A, b, P, rho)
@@ -176,13 +176,14 @@ def biconvex_solve(cnt_plan, dt, m, x_init, Qx, qx, Qf, lbx, ubx, X, F, P,
         P = P + viol
         nrm = float(np.sqrt(viol @ viol))
         hist.append(nrm)
+        trace.append((it_f, it_x, ff.n_bt, fx.n_bt))
         n_admm += 1
         if np.isnan(nrm):
             status = 2
             break
         if nrm < exit_tol:
             break
-    return dict(X=px.x, F=pf.x, P=P, L_x=fx.L, L_f=ff.L, hist=np.array(hist),
+    return dict(X=px.x, F=pf.x, P=P, L_x=fx.L, L_f=ff.L, hist=np.array(hist), trace=np.array(trace, dtype=np.int64).reshape(-1, 4),
                 stats=np.array([n_admm, it_f, it_x, ff.n_bt, fx.n_bt, status]))
 
 

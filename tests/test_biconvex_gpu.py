@@ -79,7 +79,7 @@ def test_hundred_admm_iterations(oracle):
 
 
 GOLDEN = sorted(p for p in __import__("glob").glob(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "*.npz"))
-                if not __import__("os").path.basename(p).startswith("ik_"))       # ik_*: whole-body fixtures (tests/test_ik_gpu.py)
+                if not __import__("os").path.basename(p).startswith(("ik_", "chaos_")))   # ik_*: whole-body fixtures (tests/test_ik_gpu.py); chaos_*: CPU ensembles
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[__import__("os").path.basename(p)[:-4] for p in GOLDEN])
@@ -234,6 +234,44 @@ def test_diverging_problem_does_not_poison_neighbours(oracle, mapping, which):
             assert np.array_equal(got[k][i], clean[k][i]), (i, k)
     ref = oracle.solve_batch(bad.slice(1, 2), num_iters=4)
     assert ref["stats"][0, 5] == 2 and ref["stats"][0, 0] == 1
+
+
+@pytest.mark.parametrize("which,H,precision", [("batch", 40, "f64"), ("batch", 40, "f32"), ("batch", 20, "f64"), ("batch", 20, "f32"),
+                                               ("wave", 20, "f64"), ("batch", 15, "f64")])
+def test_go2_at_the_references_mu_1_diverges_as_the_oracle(oracle, mapping, which, H, precision):
+    """The reference's friction coefficient is fixed at mu = 1 (fista.hpp:60; the setter is not bound,
+    srcpy/motion_planner/biconvex.cpp:19-44).  For the 15 kg synthetic Go2 its squared-norm "SoC" projection (fista.cpp:52-70) is
+    expansive enough that the force FISTA overflows to NaN within the first or second ADMM iteration: BiConvexMP::optimize prints
+    "solver diverged" and returns with the NaNs in place (biconvex.cpp:106-109).  The NATURAL divergence, through both centroidal
+    kernels (one knot per lane with 1 / 2 / 4 problems per wave, one problem per wave) and both precisions: status 2, the
+    oracle's ADMM count (1 or 2), the oracle's iteration counters and its NaN pattern in F -- and contact-free neighbours in the
+    same batch (every fifth problem: no force, nothing for the projection to act on) untouched: bit for bit what they are in a
+    batch at mu = 10."""
+    mapping(which)
+    B = 40
+    b = problems.make_batch("go2_bound", B, H=H)
+    b.cnt_plan[::5, :, :, 0] = 0.0
+    free = np.zeros(B, bool)
+    free[::5] = True
+    b.mu = 1.0
+    ref = oracle.solve_batch(b, num_iters=10)
+    assert np.all(ref["stats"][~free, 5] == 2) and set(ref["stats"][~free, 0].tolist()) <= {1, 2, 3} and np.all(ref["stats"][free, 5] == 0)
+    got = bb.solve_host(b, num_iters=10, precision=precision)
+    name = bb._lib.lib().bmpc_biconvex_last_kernel_name()
+    assert name == {"wave": b"biconvex_latency_kernel", "batch": b"biconvex_admm_kernel" if precision == "f64" else b"biconvex_admm_kernel_f32"}[which]
+    assert np.array_equal(got["stats"][:, 5], ref["stats"][:, 5])                  # status 2 exactly where the oracle diverges
+    if precision == "f64":
+        assert np.array_equal(got["stats"], ref["stats"])                          # ... after the same ADMM / FISTA iterations
+        assert np.array_equal(np.isnan(got["F"]), np.isnan(ref["F"]))              # ... leaving the NaNs where the oracle leaves them
+    else:
+        assert np.all(got["stats"][~free, 0] <= 3)
+    assert np.all(np.isnan(got["F"][~free]).any(axis=1)) and np.all(np.isnan(got["dyn_viol"][~free]))
+    b.mu = 10.0
+    calm = bb.solve_host(b, num_iters=10, precision=precision)
+    assert np.all(calm["stats"][:, 5] == 0)
+    for k in "XFP":
+        assert np.array_equal(got[k][free], calm[k][free]), k
+    assert np.array_equal(got["stats"][free], calm["stats"][free]) and np.all(got["F"][free] == 0.0)
 
 
 @pytest.mark.parametrize("which", ["batch", "wave"])

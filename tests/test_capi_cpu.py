@@ -22,7 +22,7 @@ def test_header_and_binding_list_the_same_symbols(hiplib):
     assert declared == set(_lib.exported_symbols())
     for name in declared:
         assert hasattr(hiplib, name), name          # dlsym of each declared entry point
-    assert hiplib.bmpc_abi_version() == 1
+    assert hiplib.bmpc_abi_version() == 2
     assert hiplib.bmpc_batch_struct_size() == C.sizeof(_lib.Batch)
 
 

@@ -14,7 +14,7 @@ from oracle import oracle_np
 from tests.util import rel_l2
 
 GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
-                if not os.path.basename(p).startswith("ik_"))                      # ik_*: whole-body fixtures (tests/test_ik_twin_cpu.py)
+                if not os.path.basename(p).startswith(("ik_", "chaos_")))          # ik_*: whole-body fixtures (tests/test_ik_twin_cpu.py); chaos_*: ensembles (below)
 
 
 def _np_solve(b, i, ref, iters):
@@ -192,3 +192,45 @@ def test_matrix_free_cpu_variant_agrees_with_the_strict_restatement(oracle):
     f = oracle.solve_batch(b, num_iters=10, fast=True)
     assert np.array_equal(a["stats"][:, [0, 5]], f["stats"][:, [0, 5]])
     assert np.all(rel_l2(f["X"], a["X"]) < 5e-3)
+
+
+def test_per_iteration_history_agrees_between_the_restatements(oracle):
+    """hist / trace (dynamics violation and running FISTA iteration / retry counts after every ADMM iteration): the strict C
+    oracle, the matrix-free C variant and the numpy twin leave the same discrete path and the same violations on calm problems;
+    the totals of the last row are the stats."""
+    b = problems.make_batch("solo12_trot", 4)
+    ref = oracle.solve_batch(b, num_iters=10, trace=True)
+    fast = oracle.solve_batch(b, num_iters=10, trace=True, fast=True)
+    assert np.array_equal(ref["trace"], fast["trace"])
+    assert np.allclose(ref["hist"], fast["hist"], rtol=1e-10, atol=0)
+    for i in range(b.B):
+        n = int(ref["stats"][i, 0])
+        assert np.array_equal(ref["trace"][i, n - 1], ref["stats"][i, [1, 2, 3, 4]]) and np.all(ref["trace"][i, n:] == -1)
+        assert np.all(np.diff(ref["trace"][i, :n], axis=0) >= 0)
+        rn = _np_solve(b, i, ref, 10)
+        assert np.array_equal(rn["trace"], ref["trace"][i, :n]) and np.allclose(rn["hist"], ref["hist"][i, :n], rtol=1e-10, atol=0)
+
+
+@pytest.mark.parametrize("name,config,H,iters", [("solo12_mixed", "solo12_mixed", None, 10), ("go2_bound_h40", "go2_bound", 40, 10)])
+def test_committed_chaos_ensembles_reproduce(oracle, name, config, H, iters):
+    """tests/golden/chaos_<name>.npz (tools/chaos_ensemble.py): the C members of the per-problem ensembles, re-run here on every
+    fourth sampled problem, give the committed k_calm / spreads / strict history exactly -- the perturbations are a function of
+    (seed, problem index, member) alone.  And the file tells what the ensembles are for: problem 2304 of solo12_mixed (the one
+    round 3's full-size test went red on) leaves the common path in ADMM iteration 7 and spreads to ~1e-3 on the CPU alone."""
+    from tests.util import chaos_ensemble
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "chaos_%s.npz" % name))
+    pick = np.arange(0, len(g["sub"]), 4)
+    if name == "solo12_mixed":
+        i2304 = int(np.where(g["sub"] == 2304)[0][0])
+        assert g["k_calm"][i2304] == 7 and 5e-4 < g["spread"][i2304] < 5e-3
+        assert np.all(g["hist_spread"][i2304, :7] < 1e-13) and g["hist_spread"][i2304, 7] > 1e-5
+        pick = np.union1d(pick, [i2304])
+    sub = g["sub"][pick]
+    b = problems.make_batch(config, 4096, H=H) if H else problems.make_batch(config, 4096)
+    ref, ens = chaos_ensemble(b.take(sub), sub, iters, oracle)
+    assert np.array_equal(ref["trace"], g["ref_trace"][pick]) and np.array_equal(ref["hist"], g["ref_hist"][pick], equal_nan=True)
+    assert np.array_equal(ens["k_calm"], g["k_calm_c"][pick])
+    assert np.allclose(ens["spread"], g["spread_c"][pick], rtol=1e-9, atol=0)
+    assert np.allclose(ens["hist_spread"], g["hist_spread_c"][pick], rtol=1e-9, atol=0)
+    # the numpy twin can only widen an ensemble
+    assert np.all(g["k_calm"] <= g["k_calm_c"]) and np.all(g["spread"] >= g["spread_c"])

@@ -13,9 +13,10 @@ import pytest
 
 from bunmpc_amd import batch as bb
 from bunmpc_amd import problems, urdf_model
-from tests.util import cpu_spread, rel_l2, within_envelope, within_population_envelope
+from tests.util import chaos_ensemble, cpu_spread, prefix_parity, rel_l2, within_envelope
 
 pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ROBOTS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bunmpc_amd", "robots")
 
 # fp32 tolerance against the fp64 CPU oracle.  The iterates are fp32 (unit round-off 6e-8) through ~2 500 FISTA iterations per
@@ -53,6 +54,33 @@ def test_fp32_kernel_against_the_cpu_oracle(oracle, config, B, H):
         A, bf = oracle.dense_A_f(b.cnt_plan[i], b.dt[i], b.m, got["F"][i], b.x_init[i])
         r = np.linalg.norm(A @ got["X"][i] - bf)
         assert abs(r - got["dyn_viol"][i]) <= 1e-4 * max(r, 1e-3), (i, r, got["dyn_viol"][i])
+
+
+def _sampled_prefix_parity(name, b, sub, iters, got, oracle, label, calm_tol=1e-12):
+    """The GPU's sampled problems against the strict oracle under the per-problem CPU ensembles of tests/golden/chaos_<name>.npz
+    (tools/chaos_ensemble.py; tests/util.py::prefix_parity): exact discrete path and violation to 1e-9 before the reference
+    algorithm's own bifurcation, the problem's OWN ensemble range after it.  The ensemble is recomputed here from the C members
+    and must reproduce the committed file (the numpy twin's contribution comes from the file)."""
+    g = np.load(os.path.join(GOLDEN, "chaos_%s.npz" % name))
+    assert np.array_equal(g["sub"], sub) and int(g["iters"]) == iters
+    ref, ens_c = chaos_ensemble(b.take(sub), sub, iters, oracle)
+    assert np.array_equal(ref["trace"], g["ref_trace"]) and np.array_equal(ref["hist"], g["ref_hist"], equal_nan=True)
+    assert np.array_equal(ens_c["k_calm"], g["k_calm_c"]) and np.allclose(ens_c["spread"], g["spread_c"], rtol=1e-9, atol=0)
+    ens = dict(k_calm=g["k_calm"], hist_spread=g["hist_spread"], spread=g["spread"])
+    ok, rep = prefix_parity({k: got[k][sub] for k in ("X", "F", "hist", "trace")}, ref, ens)
+    calm = ens["k_calm"] >= iters
+    ratio = rep["err"][~calm] / np.maximum(ens["spread"][~calm], 1e-300)
+    print("%s: %d sampled problems: %d calm max err %.2e | %d with a chaotic tail: calm prefixes %s ADMM iterations reproduced exactly; "
+          "final distance / own ensemble spread median %.2f max %.2f"
+          % (label, len(sub), calm.sum(), rep["err"][calm].max() if calm.any() else 0.0, (~calm).sum(), sorted(ens["k_calm"][~calm].tolist()),
+             np.median(ratio) if ratio.size else 0.0, ratio.max() if ratio.size else 0.0))
+    assert np.all(ok), {int(sub[i]): w for i, w in rep["why"].items()}
+    assert np.all(rep["err"][calm] < calm_tol)
+    assert np.array_equal(got["stats"][sub][calm], ref["stats"][calm])      # calm problems: the oracle's whole discrete path
+    assert np.array_equal(got["stats"][sub][:, 5], ref["stats"][:, 5])
+    if iters <= 10:
+        assert np.array_equal(got["stats"][sub][:, 0], ref["stats"][:, 0])  # (at 100 iterations a chaotic problem may cross exit_tol an iteration apart)
+    return ref, ens
 
 
 def _go2_wb(B, first=0):
@@ -121,7 +149,7 @@ def test_full_size_go2_bound_h40(oracle, precision):
     the reference algorithm NaNs for a 15 kg robot at mu = 1, tests/test_oracle_cpu.py.)"""
     B = 4096
     b = problems.make_batch("go2_bound", B, H=40)
-    dev = bb.DeviceBatch(b, num_iters=10, precision=precision)
+    dev = bb.DeviceBatch(b, num_iters=10, precision=precision, keep_hist=True)
     dev.solve()
     got = dev.results()
     _centroidal_invariants(b, got, oracle, b.mu)
@@ -130,14 +158,14 @@ def test_full_size_go2_bound_h40(oracle, precision):
     for k in "XFP":
         assert np.array_equal(again[k], got[k])                       # deterministic reductions: bit-identical re-solve
     sub = np.arange(0, B, 64)
-    ref, spread = cpu_spread(b.take(sub), 10, oracle)
-    err, bound = within_envelope({k: got[k][sub] for k in "XF"}, ref, spread)
-    assert np.array_equal(got["stats"][sub][:, [0, 5]], ref["stats"][:, [0, 5]])
-    print("go2_bound H=40 B=4096 %s: sampled parity median %.2e max %.2e; CPU spread max %.2e" % (precision, np.median(err), err.max(), spread.max()))
     if precision == "f64":
-        assert np.all(err <= bound) and np.median(err) < 1e-12
+        _sampled_prefix_parity("go2_bound_h40", b, sub, 10, got, oracle, "go2_bound H=40 B=4096 f64")
     else:
+        ref, spread = cpu_spread(b.take(sub), 10, oracle, with_numpy=False)
+        err = np.maximum(rel_l2(got["X"][sub], ref["X"]), rel_l2(got["F"][sub], ref["F"]))
+        assert np.array_equal(got["stats"][sub][:, [0, 5]], ref["stats"][:, [0, 5]])
         calm = spread <= 1e-9
+        print("go2_bound H=40 B=4096 f32: sampled parity calm %d problems median %.2e max %.2e" % (calm.sum(), np.median(err[calm]), err[calm].max()))
         assert np.median(err[calm]) <= FP32_MEDIAN and np.all(err[calm] <= FP32_MAX)
 
 
@@ -149,7 +177,7 @@ def test_full_size_solo12_mixed(oracle, precision):
     B = 4096
     b = problems.make_batch("solo12_mixed", B)
     assert b.W_X.shape[0] == B and len(set(b.gait_id.tolist())) == 3          # the per-problem-weights path, all three gaits
-    dev = bb.DeviceBatch(b, num_iters=10, precision=precision)
+    dev = bb.DeviceBatch(b, num_iters=10, precision=precision, keep_hist=True)
     dev.solve()
     got = dev.results()
     assert bb._lib.lib().bmpc_biconvex_last_kernel_name() == (b"biconvex_admm_kernel" if precision == "f64" else b"biconvex_admm_kernel_f32")
@@ -159,18 +187,18 @@ def test_full_size_solo12_mixed(oracle, precision):
     for k in "XFP":
         assert np.array_equal(again[k], got[k])
     sub = np.arange(0, B, 64)
-    ref, spread = cpu_spread(b.take(sub), 10, oracle)
-    err, bound = within_envelope({k: got[k][sub] for k in "XF"}, ref, spread)
-    assert np.array_equal(got["stats"][sub][:, [0, 5]], ref["stats"][:, [0, 5]])
-    calm = spread <= 1e-9
-    print("solo12_mixed B=4096 %s: sampled parity calm %d problems max %.2e | chaotic %d problems max %.2e (CPU spread max %.2e)"
-          % (precision, calm.sum(), err[calm].max() if calm.any() else 0.0, (~calm).sum(), err[~calm].max() if (~calm).any() else 0.0, spread.max()))
     if precision == "f64":
-        err, bound, own = within_population_envelope({k: got[k][sub] for k in "XF"}, ref, spread)
-        assert np.all(err <= bound) and own >= 0.9, (err[err > bound], own)
-        assert np.all(err[calm] < 1e-12)
-        assert np.array_equal(got["stats"][sub][calm], ref["stats"][calm])    # calm problems: the oracle's whole discrete path
+        # problem 2304 is the one round 3's first run of this test went red on (1.2e-3 from the strict oracle where three CPU
+        # restatements agreed to 8e-5): its ensemble leaves the common path in ADMM iteration 7 (the violation's range jumps from
+        # 3e-15 to 1e-4 within that iteration's force FISTA, fista.cpp:38 / :52-70) and spreads to 1.3e-3 -- the GPU is one more
+        # member.  Its first seven ADMM iterations are reproduced exactly.
+        _sampled_prefix_parity("solo12_mixed", b, sub, 10, got, oracle, "solo12_mixed B=4096 f64")
     else:
+        ref, spread = cpu_spread(b.take(sub), 10, oracle, with_numpy=False)
+        err = np.maximum(rel_l2(got["X"][sub], ref["X"]), rel_l2(got["F"][sub], ref["F"]))
+        assert np.array_equal(got["stats"][sub][:, [0, 5]], ref["stats"][:, [0, 5]])
+        calm = spread <= 1e-9
+        print("solo12_mixed B=4096 f32: sampled parity calm %d problems median %.2e max %.2e" % (calm.sum(), np.median(err[calm]), err[calm].max()))
         assert np.median(err[calm]) <= FP32_MEDIAN and np.all(err[calm] <= FP32_MAX)
 
 
@@ -251,3 +279,53 @@ def test_full_size_go2_h60_kinodyn(oracle):
     ref, spread = cpu_spread(wb.dyn.take(sub[:8]), 10, oracle)
     err, bound = within_envelope({k: g[k][sub[:8]] for k in "XF"}, ref, spread)
     assert np.all(err <= bound), (err, bound)
+
+
+def test_the_references_own_call_at_scale_100_admm_iterations(oracle):
+    """kd.optimize(q, v, 100, 1) -- the call the reference's generator makes every 50 ms (abstract_cyclic_gen.py:663) -- as a
+    batch of BASELINE's size: B = 4096 Solo12 trot, full KinoDynMP.optimize (centroidal ADMM at num_iters = 100 + whole-body
+    IK-DDP).  At 100 iterations the ADMM's early exit (||A_f X - b_f|| < 1e-3, biconvex.cpp:111-114) makes the iteration count
+    differ per problem, and a fifth of the problems reach the chaotic regime of the force FISTA (tests/util.py).  Invariants on
+    every problem; on a 64-problem sample the prefix check against the strict oracle under the committed per-problem ensembles
+    (the oracle's exact ADMM / FISTA counts on calm problems); the IK-DDP on the GPU's own centroidal solution against the
+    compiled CPU twin."""
+    from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
+    from oracle import ik_oracle_c as ic
+    B, N = 4096, 100
+    model = urdf_model.RobotModel.from_json(open(os.path.join(ROBOTS, "solo12.json")).read())
+    wb = problems.make_wb_batch(model, B)
+    kb = KinoDynDeviceBatch(wb, model, num_iters=N, keep_hist=True)
+    kb.solve()
+    g = kb.results()
+    H, T = wb.dyn.H, wb.ik_T
+    n_admm = g["stats"][:, 0]
+    assert np.all(g["stats"][:, 5] == 0) and np.all(np.isfinite(g["X"])) and np.all(np.isfinite(g["F"]))
+    early = n_admm < N
+    assert 0.5 < early.mean() and np.all(g["dyn_viol"][early] < 1e-3)     # the exit rule itself
+    assert len(np.unique(n_admm)) > 10                                   # ... and it does make the counts differ per problem
+    hist = g["hist"]
+    for i in range(0, B, 97):                                            # the history: one row per iteration run, NaN after
+        assert np.all(np.isfinite(hist[i, :n_admm[i]])) and np.all(np.isnan(hist[i, n_admm[i]:])) and hist[i, n_admm[i] - 1] == g["dyn_viol"][i]
+        assert np.array_equal(g["trace"][i, n_admm[i] - 1], g["stats"][i, 1:5])
+    F = g["F"].reshape(B, H, 4, 3)
+    assert np.all(F[wb.dyn.cnt_plan[..., 0] == 0] == 0.0) and np.all(F[..., 2] >= 0)
+    assert np.all(F[..., 0] ** 2 + F[..., 1] ** 2 <= wb.dyn.mu * F[..., 2] * (1 + 1e-6) + 1e-9)
+    st = g["ik_status"]
+    assert set(np.unique(st).tolist()) <= {0, 1} and np.all(g["ik_stop"][st == 0] < 1e-9) and (st == 1).mean() < 0.01
+    assert np.array_equal(g["xs"][:, 0], wb.x)
+    # sampled parity, centroidal part: x_init as the CPU twin computes it from (q, v) (kino_dyn.cpp:42)
+    m = ic.Model(model)
+    sub = np.arange(0, B, 64)
+    wb.dyn.x_init[:] = ic.centroidal_state(m, wb.x)
+    _sampled_prefix_parity("kinodyn_solo12_n100", wb.dyn, sub, N, g, oracle, "KinoDyn solo12 B=4096 num_iters=100", calm_tol=1e-10)
+    # whole-body part: the CPU twin on the GPU's own centroidal solution
+    r = ic.solve_wb_batch(m, wb.take(sub), g["X"][sub])
+    assert np.array_equal(r["iters"], g["ik_iters"][sub]) and np.array_equal(r["status"], st[sub])
+    assert np.all(np.abs(r["cost"] - g["ik_cost"][sub]) <= 1e-8 * np.abs(r["cost"]))
+    e = rel_l2(g["xs"][sub].reshape(len(sub), -1), r["xs"].reshape(len(sub), -1))
+    print("KinoDyn n100 B=4096: ADMM iterations min %d median %d max %d (%d%% exit early); DDP iterations mean %.1f; sampled xs rel-L2 vs CPU twin max %.2e"
+          % (n_admm.min(), np.median(n_admm), n_admm.max(), 100 * early.mean(), g["ik_iters"].mean(), e.max()))
+    assert np.all(e < 1e-6)
+    kb.solve()
+    g2 = kb.results()
+    assert np.array_equal(g2["X"], g["X"]) and np.array_equal(g2["xs"], g["xs"]) and np.array_equal(g2["trace"], g["trace"])
