@@ -774,10 +774,10 @@ int bmpc_ik_centroidal_state_device(const bmpc_model_t *model, const double *x, 
     HIP_TRY(bunmpc::ik_launch_centroidal_state(m->dptr(), x, out9, B, static_cast<hipStream_t>(hip_stream)));
     return BMPC_OK;
 }
-void bmpc_ik_layout(int n_col, long *offsets8) {   // xs, us, scal, K, kff, fs, Lx, Lxx offsets for callers that read the workspace
+void bmpc_ik_layout(int n_col, long *offsets8) {   // xs, us, scal, K, kff, fs, Lx, Lqq offsets for callers that read the workspace
     const bunmpc::IkLayout L = bunmpc::IkLayout::make(n_col);
     offsets8[0] = L.xs; offsets8[1] = L.us; offsets8[2] = L.scal; offsets8[3] = L.K; offsets8[4] = L.kff;
-    offsets8[5] = L.fs; offsets8[6] = L.Lx; offsets8[7] = L.Lxx;
+    offsets8[5] = L.fs; offsets8[6] = L.Lx; offsets8[7] = L.Lqq;
 }
 
 int bmpc_ik_set_gains_wave_below(int n_active) { return g_gains_wave_below.exchange(n_active); }

@@ -40,10 +40,6 @@
 #include "rbd_quad.h"
 #include "lds_batch.h"
 
-#ifndef BWD_PREFETCH_ROW
-#define BWD_PREFETCH_ROW 0
-#endif
-
 namespace bunmpc {
 namespace {
 
@@ -417,6 +413,10 @@ __device__ __forceinline__ void calc_assemble(const IkBatchArgs &a, long b, int 
             lds_read_b128x11(lds_offset(q.Jt[j]), own);
             UNROLL_RBD for (int k = 0; k < kRes; ++k) jw[k] = (k & 1) ? own[k >> 1].y : own[k >> 1].x;
         }
+        {   // the momentum Jacobian M = d h_g / d (q, v), row-major, for the Riccati pass (IkLayout: kHnDoubles): lane j = column j
+            double *Hn = ws + L.Hn + (long)t * kHnDoubles;
+            UNROLL_RBD for (int k = 0; k < 6; ++k) Hn[k * kNDX + j] = jw[k];
+        }
         UNROLL_RBD for (int k = 0; k < 6; ++k) jw[k] *= wm;
         UNROLL_RBD for (int k = 0; k < 3; ++k) jw[6 + k] *= wc;
         UNROLL_RBD for (int f = 0; f < kFrameSlots; ++f)
@@ -429,53 +429,50 @@ __device__ __forceinline__ void calc_assemble(const IkBatchArgs &a, long b, int 
         else g += wst * state_w[j] * q.rs[j];
         ws[L.Lx + (long)t * kNDX + j] = sc * g;
     }
-    // Gauss-Newton L_xx = J^T W J (+ the state regularisation: its Jlog6 block on the free-flyer, its weights on the rest of
-    // the diagonal) on the matrix pipe: 3 x 3 tiles of v_mfma_f64_16x16x4 over the 21 residual rows (24 with padding), the
-    // rows of Jt in LDS serving as both operands (A weighted).  Lane l holds A[l & 15][k = l >> 4], B[k][l & 15] and
-    // D[(l >> 4) + 4 v][l & 15]; as in the Riccati pass' Schur update this is about instruction count and LDS traffic
-    // (every lane read two rows of Jt by broadcast per two output rows before), not about flops.
+    // Gauss-Newton L_xx = sc J^T W J (+ the state regularisation).  Only its q-block WITHOUT the momentum rows is formed here:
+    //     L_qq' = J_c^T wc J_c + sum_f J_f^T w_f J_f + (state regularisation on q: Jlog6 block on the free-flyer, weights on the joints)
+    // on the matrix pipe, three tiles of v_mfma_f64_16x16x4 over the residual rows 6..20 (k-steps 1..5; the momentum rows 0..5 get
+    // weight zero), the rows of Jt in LDS serving as both operands (A weighted).  Lane l holds A[l & 15][k = l >> 4], B[k][l & 15] and
+    // D[(l >> 4) + 4 v][l & 15].  The momentum term wm M^T M -- the only part of L_xx that reaches the velocity columns -- is added
+    // by the Riccati pass itself from M (stored above), in the same tile layout its Schur update runs in; the tiles go to the
+    // workspace AS TILES (IkLayout: kLqqDoubles), each store instruction one contiguous 512 / 64 / 32 bytes.
     {
         const int li = lane & 15, lk = lane >> 4;
         double av[18], bv[18];      // [6 I + ks]: Jt[16 I + li][4 ks + lk]
         lds_read_calc_operand(lds_offset(&q.Jt[0][0]) + (unsigned)(li * kResLd + lk) * 8u, bv);
-        UNROLL_RBD for (int ks = 0; ks < 6; ++ks) {
+        UNROLL_RBD for (int ks = 1; ks < 6; ++ks) {
             const int k = 4 * ks + lk;                       // residual row this lane feeds in k-step ks
             const int f = k >= 9 ? (k - 9) / 3 : 0;
             const double fw = f == 0 ? tk.frame_w(0) : f == 1 ? tk.frame_w(1) : f == 2 ? tk.frame_w(2) : tk.frame_w(3);
-            const double w = k < 6 ? wm : k < 9 ? wc : k < kRes ? fw : 0.0;
-            UNROLL_RBD for (int I = 0; I < 3; ++I) {
+            const double w = k < 6 ? 0.0 : k < 9 ? wc : k < kRes ? fw : 0.0;
+            UNROLL_RBD for (int I = 0; I < 2; ++I) {
                 if (ks == 5) bv[6 * I + ks] = k < kRes ? bv[6 * I + ks] : 0.0;     // columns 21..23 are padding / the next row
                 av[6 * I + ks] = w * bv[6 * I + ks];
             }
         }
-        double *Lxx = ws + L.Lxx + (long)t * kNDX * kNDX;
-        double swj[3];
-        UNROLL_RBD for (int J = 0; J < 3; ++J) { const int jj = 16 * J + li; swj[J] = jj >= 6 && jj < kNDX ? wst * state_w[jj] : 0.0; }
-        UNROLL_RBD for (int I = 0; I < 3; ++I) {             // one block row of tiles at a time: three accumulators live
-            mfma_acc_t acc[3];
-            UNROLL_RBD for (int J = 0; J < 3; ++J) acc[J] = mfma_acc_t{0.0, 0.0, 0.0, 0.0};
-            UNROLL_RBD for (int ks = 0; ks < 6; ++ks)
-                UNROLL_RBD for (int J = 0; J < 3; ++J)
-                    if (ks < 2 || (I < 2 && J < 2))        // rows / columns 32..35 are velocity columns of J: only the momentum rows k < 6
-                        acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[6 * I + ks], bv[6 * J + ks], acc[J], 0, 0, 0);
-            if (I == 0) {
-                UNROLL_RBD for (int ks = 0; ks < 2; ++ks) {  // the Jlog6 block: rows / columns 0..5 of tile (0, 0)
-                    const int k = 4 * ks + lk;
-                    const bool ok = li < 6 && k < 6;
-                    const double jl = q.JlT[ok ? li : 0][ok ? k : 0], swk = state_w[ok ? k : 0];
-                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? wst * swk * jl : 0.0, ok ? jl : 0.0, acc[0], 0, 0, 0);
-                }
-            }
-            UNROLL_RBD for (int J = 0; J < 3; ++J) {
-                const int jj = 16 * J + li;
-                if (jj < kNDX) {
-                    UNROLL_RBD for (int v = 0; v < 4; ++v) {
-                        const int i = 16 * I + lk + 4 * v;
-                        if (i < kNDX) Lxx[(long)i * kNDX + jj] = sc * (acc[J][v] + (i == jj ? swj[J] : 0.0));
-                    }
-                }
-            }
+        double *Lqq = ws + L.Lqq + (long)t * kLqqDoubles;
+        mfma_acc_t a00 = mfma_acc_t{0.0, 0.0, 0.0, 0.0}, a01 = a00, a11 = a00;
+        UNROLL_RBD for (int ks = 1; ks < 6; ++ks) {
+            a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], a00, 0, 0, 0);
+            a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[6 + ks], a01, 0, 0, 0);
+            a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[6 + ks], bv[6 + ks], a11, 0, 0, 0);
         }
+        UNROLL_RBD for (int ks = 0; ks < 2; ++ks) {  // the Jlog6 block: rows / columns 0..5 of tile (0, 0)
+            const int k = 4 * ks + lk;
+            const bool ok = li < 6 && k < 6;
+            const double jl = q.JlT[ok ? li : 0][ok ? k : 0], swk = state_w[ok ? k : 0];
+            a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? wst * swk * jl : 0.0, ok ? jl : 0.0, a00, 0, 0, 0);
+        }
+        const double sw0 = li >= 6 ? wst * state_w[li] : 0.0;            // the joints' part of the diagonal of tile (0, 0)
+        const double sw1 = wst * state_w[16 + (li < 2 ? li : 0)];        // ... of the 2 x 2 corner of tile (1, 1) (q 16, 17)
+        UNROLL_RBD for (int v = 0; v < 4; ++v) Lqq[v * 64 + lane] = sc * (a00[v] + (lk + 4 * v == li ? sw0 : 0.0));
+        if (li < 2) { UNROLL_RBD for (int v = 0; v < 4; ++v) Lqq[256 + (v * 4 + lk) * 2 + li] = sc * a01[v]; }
+        if (li < 2 && lk < 2) Lqq[288 + lk * 2 + li] = sc * (a11[0] + (lk == li ? sw1 : 0.0));
+        // the momentum weight and the velocity part of the state regularisation's diagonal, as the tiles (1,1) / (2,2) index it
+        double *Hn = ws + L.Hn + (long)t * kHnDoubles;
+        if (lane < 16) Hn[kHnD11 + lane] = lane >= 2 ? sc * wst * state_w[16 + lane] : 0.0;
+        else if (lane < 20) Hn[kHnD22 + lane - 16] = sc * wst * state_w[16 + lane];
+        else if (lane == 20) Hn[kHnW] = sc * wm;
     }
 }
 
@@ -676,6 +673,62 @@ __device__ __forceinline__ double rcp64(double b) {
     double r = __builtin_amdgcn_rcp(b);
     r = fma(fma(-b, r, 1.0), r, r);
     return fma(fma(-b, r, 1.0), r, r);
+}
+
+// What a lane needs of node t's compact L_xx (IkLayout: Lqq tiles, Hn) for its elements of the six upper MFMA tiles: 18 loads,
+// each wave instruction over contiguous bytes (the full row it replaces: 36 loads with a 288-byte lane stride).
+struct LxxLane { double lq[9], mb[6], w, d11, d22; };
+__device__ __forceinline__ void lxx_lane_load(const double *ws, const IkLayout &L, int t, int lane, LxxLane &o) {
+    const int li = lane & 15, lk = lane >> 4;
+    const double *Lqq = ws + L.Lqq + (long)t * kLqqDoubles, *Hn = ws + L.Hn + (long)t * kHnDoubles;
+    UNROLL_RBD for (int v = 0; v < 4; ++v) o.lq[v] = Lqq[v * 64 + lane];
+    const int c = li < 2 ? li : 0;          // (every lane loads an existing element; what is not its own is replaced by zero)
+    UNROLL_RBD for (int v = 0; v < 4; ++v) { const double x = Lqq[256 + (v * 4 + lk) * 2 + c]; o.lq[4 + v] = li < 2 ? x : 0.0; }
+    { const double x = Lqq[288 + (lk & 1) * 2 + c]; o.lq[8] = li < 2 && lk < 2 ? x : 0.0; }
+    UNROLL_RBD for (int ks = 0; ks < 2; ++ks)
+        UNROLL_RBD for (int J = 0; J < 3; ++J) {
+            const int k = 4 * ks + lk, j = 16 * J + li;
+            const bool ok = k < 6 && j < kNDX;
+            const double x = Hn[(ok ? k : 0) * kNDX + (ok ? j : 0)];
+            o.mb[3 * ks + J] = ok ? x : 0.0;
+        }
+    o.w = Hn[kHnW];
+    o.d11 = Hn[kHnD11 + li];
+    { const double x = Hn[kHnD22 + (li & 3)]; o.d22 = li < 4 ? x : 0.0; }
+}
+// acc (the six tiles on and above the block diagonal, numbered as in the Schur update) += L_xx of the node
+__device__ __forceinline__ void lxx_add_tiles(mfma_acc_t (&acc)[6], const LxxLane &x, int lane) {
+    const int li = lane & 15, lk = lane >> 4;
+    UNROLL_RBD for (int v = 0; v < 4; ++v) {
+        acc[0][v] += x.lq[v];
+        acc[1][v] += x.lq[4 + v];
+        acc[3][v] += lk + 4 * v == li ? x.d11 : 0.0;          // velocity diagonal inside tile (1, 1): columns 18..31
+    }
+    acc[3][0] += x.lq[8];
+    acc[5][0] += lk == li ? x.d22 : 0.0;                     // ... inside tile (2, 2): columns 32..35
+    UNROLL_RBD for (int ks = 0; ks < 2; ++ks)                 // wm M^T M: six momentum rows = two k-steps (rows 6, 7 are zero)
+        UNROLL_RBD for (int I = 0; I < 3; ++I)
+            UNROLL_RBD for (int J = I; J < 3; ++J) {
+                const int tl = (I == 0 ? 0 : I == 1 ? 2 : 3) + J;
+                acc[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.w * x.mb[3 * ks + I], x.mb[3 * ks + J], acc[tl], 0, 0, 0);
+            }
+}
+// the six tiles -> the staged rows N (mirror image of the off-diagonal tiles too), xreg joining the diagonal
+__device__ __forceinline__ void tiles_to_rows(double *N, const mfma_acc_t (&acc)[6], double xreg, int lane);
+
+__device__ __forceinline__ void tiles_to_rows(double *N, const mfma_acc_t (&acc)[6], double xreg, int lane) {
+    const int li = lane & 15, lk = lane >> 4;
+    UNROLL_RBD for (int I = 0; I < 3; ++I)
+        UNROLL_RBD for (int J = I; J < 3; ++J)
+            if (J < 2 || li < kNDX - 32) {      // columns 36..47 do not exist (rows 36..47 do, as padding)
+                const int tl = (I == 0 ? 0 : I == 1 ? 2 : 3) + J;
+                UNROLL_RBD for (int v = 0; v < 4; ++v) {
+                    const int i = 16 * I + lk + 4 * v, j = 16 * J + li;
+                    // V = (V_xx + V_xx^T)/2 + xreg I: xreg joins the staged diagonal here (a diagonal entry averages with itself)
+                    N[i * LD + j] = (J == I && i == j) ? acc[tl][v] + xreg : acc[tl][v];
+                    if (J > I) N[j * LD + i] = acc[tl][v];
+                }
+            }
 }
 
 // NB = 2 (the two-wave kernel): what the gains wave needs of a node -- the factor, Y^T, y_u, the reciprocal pivots, Q_u -- is
@@ -887,7 +940,9 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
     const bool row = lane < kNDX;                  // owns row `lane` of the 36x36 matrices
     // lanes 36..53 shadow lanes 18..35 (same reads, same arithmetic, no writes): their copy of rows 18..35 of G becomes the
     // rows of Q_uu in the elimination, where lanes 18..35 themselves carry rows of Q_xu
-    const int r = row ? lane : (lane < kNDX + kNV ? lane - kNV : 0);
+    // (lanes 54..63 own nothing; their addresses point at row 4, whose LDS banks no row of their lane group uses: row 0 shares
+    // its banks with row 32 and cost every row / column read of the wave a conflict cycle)
+    const int r = row ? lane : (lane < kNDX + kNV ? lane - kNV : 4);
     const bool ul = lane >= kNV && lane < kNDX;    // owns control q = lane - 18 (rows 18..35 are the v-rows)
     const int uq = ul ? lane - kNV : 0;
     const unsigned row_addr = lds_offset(s.N + r * LD), col_addr = lds_offset(s.N + r);
@@ -899,10 +954,17 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
     for (;;) {   // computeDirection with regularisation retries (solver-ddp.cpp solve())
         bool bad = false;
         d1 = 0.0; d2 = 0.0; st = 0.0;
-        double m[kNDX];   // the one 36-wide register row: V -> N -> G -> Q_xx -> V_xx -> V
-        {
-            const double *LT = ws + L.Lxx + (long)T * kNDX * kNDX + (long)r * kNDX;
-            UNROLL_RBD for (int j = 0; j < kNDX; ++j) m[j] = LT[j] + (j == r ? xreg : 0.0);
+        double m[kNDX];   // the one 36-wide register row: V -> N -> G -> V_xx -> V
+        {   // V_T = L_xx(T) + xreg I, put together in the tile layout its compact form is made for and read back by rows
+            LxxLane lt;
+            lxx_lane_load(ws, L, T, lane, lt);
+            mfma_acc_t acc[6];
+            UNROLL_RBD for (int tl = 0; tl < 6; ++tl) acc[tl] = mfma_acc_t{0.0, 0.0, 0.0, 0.0};
+            lxx_add_tiles(acc, lt, lane);
+            tiles_to_rows(s.N, acc, xreg, lane);
+            wave_sync();
+            lds_read_row36_b64(row_addr, m);
+            wave_sync();
         }
         double vx = row ? ws[L.Lx + (long)T * kNDX + r] : 0.0;
         if (!feas) {
@@ -919,17 +981,12 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
         // and its gap -- is requested ONE NODE AHEAD: issued at the top of node t + 1, it has the whole of that node (~20K cycles)
         // to arrive.  Loaded at the top of its own node the row had ~5K cycles before its first use and the small vectors none
         // (a global-memory latency exposed twice per node: 3.4K + 2.1K of 22.5K cycles, tools/bwd_profile.py).
-        double lr[kNDX], lx_t, lu_t, luu_t, a6_t, b6_t, fs_t, dt;
-        auto fetch_node = [&](int t, double (&o_lr)[kNDX], double &o_lx, double &o_lu, double &o_luu, double &o_a6, double &o_b6, double &o_fs,
-                              double &o_dt) {
+        double lx_t, lu_t, luu_t, a6_t, b6_t, fs_t, dt;
+        auto fetch_node = [&](int t, double &o_lx, double &o_lu, double &o_luu, double &o_a6, double &o_b6, double &o_fs, double &o_dt) {
             o_dt = a.dt[b * T + t];
             o_lx = row ? ws[L.Lx + (long)t * kNDX + r] : 0.0;
             o_lu = ul ? ws[L.Lu + (long)t * kNV + uq] : 0.0;
             o_luu = lane >= kNDX && lane < kNDX + kNV ? ws[L.Luu + (long)t * kNV + lane - kNDX] : 0.0;   // on the lane of Q_uu row p
-#if BWD_PREFETCH_ROW
-            const double *Lr = ws + L.Lxx + (long)t * kNDX * kNDX + (long)r * kNDX;
-            UNROLL_RBD for (int j = 0; j < kNDX; ++j) o_lr[j] = Lr[j];
-#endif
             o_a6 = lane < 36 ? ws[L.A6 + (long)t * 36 + lane] : 0.0;
             o_b6 = lane < 36 ? ws[L.B6 + (long)t * 36 + lane] : 0.0;
             o_fs = row ? ws[L.fs + (long)t * kNDX + r] : 0.0;
@@ -942,27 +999,24 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
             if (!have) {        // the first node of a pass; in the fused kernel also a node the producers had not finished a tick ago
                 wait_node(t);
                 if (FUSED && tk.dead) return;
-                fetch_node(t, lr, lx_t, lu_t, luu_t, a6_t, b6_t, fs_t, dt);
+                fetch_node(t, lx_t, lu_t, luu_t, a6_t, b6_t, fs_t, dt);
             }
             if (lane < 36) { s.A6[lane] = a6_t; s.B6[lane] = b6_t; }
             if (row) { s.Vx[r] = vx; s.fs[r] = fs_t; }
             const double dt_t = dt;      // (this node's; the variables above are about to be overwritten by the requests for node t - 1)
-            double nlr[kNDX], nlx = 0.0, nlu = 0.0, nluu = 0.0, na6 = 0.0, nb6 = 0.0, nfs = 0.0, ndt = 0.0;
+            double nlx = 0.0, nlu = 0.0, nluu = 0.0, na6 = 0.0, nb6 = 0.0, nfs = 0.0, ndt = 0.0;
             const bool next_there = t > 0 && (!FUSED || lds_flag(ctl->ready[t - 1]) == ctl->stamp);
-            if (next_there) fetch_node(t - 1, nlr, nlx, nlu, nluu, na6, nb6, nfs, ndt);
-#if !BWD_PREFETCH_ROW
-            {    // the row itself at the top of its own node (a node ahead it costs 72 more registers: the kernel then spills and is slower)
-                const double *Lr = ws + L.Lxx + (long)t * kNDX * kNDX + (long)r * kNDX;
-                UNROLL_RBD for (int j = 0; j < kNDX; ++j) lr[j] = Lr[j];
-            }
-#endif
+            if (next_there) fetch_node(t - 1, nlx, nlu, nluu, na6, nb6, nfs, ndt);
+            // the node's compact L_xx: requested here, used at the very end of the node (the Schur update) -- the whole node to arrive
+            LxxLane lxx;
+            lxx_lane_load(ws, L, t, lane, lxx);
             wave_sync();
             PSTAMPV(0, m[0])
             apply_FxT(m, a6_addr, b6_addr, dt_t);                  // column r of N = F_x^T V
             if (row) { UNROLL_RBD for (int i = 0; i < kNDX; ++i) s.N[i * LD + r] = m[i]; }
             wave_sync();
             PSTAMPV(1, m[0])
-            lds_read_row36(row_addr, m);                         // row r of N
+            lds_read_row36_b64(row_addr, m);                         // row r of N
             apply_FxT(m, a6_addr, b6_addr, dt_t);                  // row r of G = N F_x
             PSTAMPV(2, m[35])
             // Q_x = L_x + F_x^T V_x ;  Q_u = L_u + dt (F_x^T V_x)[v]
@@ -987,7 +1041,7 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
                 al[q] = urow ? dt_t * xq : (lane == kQuLane ? quv[q] : xq);   // Q_uu[p][q] without its diagonal term / Q_u / Q_xu
             }
             const double dgv = urow ? luu_t + xreg : 0.0;                // L_uu + reg of control p on lane 36 + p
-            if (row) { UNROLL_RBD for (int j = 0; j < kNDX; ++j) s.N[r * LD + j] = m[j] + lr[j]; }       // Q_xx row -> LDS
+            if (row) { UNROLL_RBD for (int j = 0; j < kNDX; ++j) s.N[r * LD + j] = m[j]; }       // row of G -> LDS (L_xx joins it in the tiles)
             PSTAMPV(3, al[17])
             // Pivots and the column entries every lane needs travel by v_readlane (wave-uniform, no LDS, no waiting).  A
             // non-positive or NaN pivot fails the pass (Eigen::LLT info != Success).
@@ -1071,8 +1125,18 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
                         y[q] -= ((e & 1) ? lb[e >> 1].y : lb[e >> 1].x) * y[p];
                     }
                 }
+                // The gains leave the wave HERE, before the Schur update: this kernel runs two waves per SIMD (256 registers), the
+                // other wave fills the matrix pipe's shadow, and y / Q_u are dead by the time the six accumulator tiles are live.
+                UNROLL_RBD for (int p = 0; p < kNV; ++p) { d1 += quv[p] * y[p]; st += quv[p] * quv[p]; }   // d1 = Qu.k, stop = |Qu|^2
+                if (row) {      // (the empty asm keeps the stores in program order: clustered, hipcc spills a hundred registers around them)
+                    double *Kg = ws + L.K + (long)t * kNV * kNDX + r;
+                    UNROLL_RBD for (int p = 0; p < kNV; ++p) { Kg[p * kNDX] = y[p]; asm volatile("" ::: "memory"); }
+                } else if (lane == kQuLane) {
+                    UNROLL_RBD for (int p = 0; p < kNV; ++p) ws[L.kff + (long)t * kNV + p] = y[p];
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            PSTAMPV(5, y[0])
+            PSTAMPV(5, vx)
             const int li = lane & 15, lk = lane >> 4;
             mfma_acc_t acc[6];
             {
@@ -1081,6 +1145,7 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
                 lds_read_mfma_acc_upper(lds_offset(s.N + lk * LD + li), c);
                 UNROLL_RBD for (int tl = 0; tl < 6; ++tl)
                     UNROLL_RBD for (int v = 0; v < 4; ++v) acc[tl][v] = c[4 * tl + v];
+                lxx_add_tiles(acc, lxx, lane);                 // Q_xx = G + L_xx
                 UNROLL_RBD for (int ks = 0; ks < 5; ++ks)
                     UNROLL_RBD for (int I = 0; I < 3; ++I)
                         UNROLL_RBD for (int J = I; J < 3; ++J) {
@@ -1092,30 +1157,12 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
                 improvement_and_vx();
                 if (FUSED) tick_lds(tk); else bwd_barrier();
                 ++hand;
-            } else {
-                UNROLL_RBD for (int p = 0; p < kNV; ++p) { d1 += quv[p] * y[p]; st += quv[p] * quv[p]; }   // d1 = Qu.k, stop = |Qu|^2
-                if (row) {      // (the empty asm keeps the stores in program order: clustered, hipcc spills a hundred registers around them)
-                    double *Kg = ws + L.K + (long)t * kNV * kNDX + r;
-                    UNROLL_RBD for (int p = 0; p < kNV; ++p) { Kg[p * kNDX] = y[p]; asm volatile("" ::: "memory"); }
-                } else if (lane == kQuLane) {
-                    UNROLL_RBD for (int p = 0; p < kNV; ++p) ws[L.kff + (long)t * kNV + p] = y[p];
-                }
             }
             PSTAMPV(6, vx)
-            UNROLL_RBD for (int I = 0; I < 3; ++I)
-                UNROLL_RBD for (int J = I; J < 3; ++J)
-                    if (J < 2 || li < kNDX - 32) {      // columns 36..47 do not exist (rows 36..47 do, as padding)
-                        const int tl = (I == 0 ? 0 : I == 1 ? 2 : 3) + J;
-                        UNROLL_RBD for (int v = 0; v < 4; ++v) {
-                            const int i = 16 * I + lk + 4 * v, j = 16 * J + li;
-                            // V = (V_xx + V_xx^T)/2 + xreg I: xreg joins the staged diagonal here (a diagonal entry averages with itself)
-                            s.N[i * LD + j] = (J == I && i == j) ? acc[tl][v] + xreg : acc[tl][v];
-                            if (J > I) s.N[j * LD + i] = acc[tl][v];
-                        }
-                    }
+            tiles_to_rows(s.N, acc, xreg, lane);
             wave_sync();
             PSTAMPV(7, vx)
-            lds_read_row36(row_addr, m);
+            lds_read_row36_b64(row_addr, m);
             {
                 double col[kNDX], chk = 0.0;
                 lds_read_col36_ld37(col_addr, col);
@@ -1137,9 +1184,6 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
             PSTAMPV(8, vx)
             have = next_there;
             if (next_there) {     // the node requested at the top becomes the current one
-#if BWD_PREFETCH_ROW
-                UNROLL_RBD for (int j = 0; j < kNDX; ++j) lr[j] = nlr[j];
-#endif
                 lx_t = nlx; lu_t = nlu; luu_t = nluu; a6_t = na6; b6_t = nb6; fs_t = nfs; dt = ndt;
             }
             if (bad || (FUSED && tk.dead)) break;
@@ -1186,8 +1230,11 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
     } else if (lane == kQuLane) { sc[S_D1] = d1; sc[S_D2] = d2; sc[S_STOP] = st; }   // the lane of the feed-forward terms
 }
 
+#ifndef BWD_WPE
+#define BWD_WPE 1      // waves per SIMD the Riccati kernel is compiled for (2 = a 256-register build, an experiment switch)
+#endif
 template <int NWB>
-__global__ __launch_bounds__(64 * NWB) void ik_backward_kernel(const IkBatchArgs a) {
+__global__ __launch_bounds__(64 * NWB, NWB == 1 ? BWD_WPE : 1) void ik_backward_kernel(const IkBatchArgs a) {
     __shared__ BackwardLds<NWB> s;
     const long b = slot_problem(a, blockIdx.x);
     if (b < 0) return;

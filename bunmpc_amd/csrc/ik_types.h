@@ -45,10 +45,23 @@ constexpr int kTrySlots = 12;    // 10 used by the all-step-lengths mapping (thr
 // [cost, regularisation, accepted step length (0 = none), stopping criterion] as SolverDDP holds them at the end of the iteration
 constexpr int kTraceIters = 128, kTraceDoubles = 4;
 
+// What the derivative pass hands the Riccati pass per node INSTEAD of the full Gauss-Newton L_xx (36 x 36 = 1296 doubles): the
+// reference's cost set (ISL/src/ik/{com_tasks,end_effector_tasks,regularization_costs}.cpp, action_model.cpp:60-63,82-86) gives
+//     L_xx = sc ( [L_qq' 0; 0 0]  +  wm M^T M  +  diag(0, wst sw_v) ),
+// M = d h_g / d (q, v) (6 x 36: the only residual that sees the velocities), L_qq' (18 x 18) = CoM and frame-translation
+// terms + the q-part of the state regularisation (its Jlog6 block on the free-flyer), sw_v the state weights of the velocities.
+// L_xx enters the recursion only through V_xx = (L_xx + G) - Y^T Y, a sum taken on the matrix pipe in MFMA tiles: so L_qq'
+// travels IN THAT TILE LAYOUT (kLqqDoubles: tile (0,0) as [v][lane] = 256, the two q-columns of tile (0,1) = 32, the 2 x 2
+// corner of tile (1,1) = 4, padding) and M row-major with its weight and the velocity diagonal as the tiles need it
+// (kHnDoubles: M [6][36] = 216 | sc wm | pad | d11 [16] at 224: diagonal entries of tile (1,1) by column | d22 [4] at 240: of
+// tile (2,2)).  544 doubles per node instead of 1296, none of them read with a 288-byte stride.
+constexpr int kLqqDoubles = 296, kHnDoubles = 248;
+constexpr int kHnW = 216, kHnD11 = 224, kHnD22 = 240;
+
 // Layout of the per-problem DDP workspace in HBM (doubles), T = number of running nodes.
 struct IkLayout {
     int T;
-    long xs, us, xs_try, us_try, fs, xnext, Lx, Lxx, Lu, Luu, A6, B6, K, kff, Qu, Quuk, scal, nrs, njl, ncs, trace, votes, arrive, total;
+    long xs, us, xs_try, us_try, fs, xnext, Lx, Lqq, Hn, Lu, Luu, A6, B6, K, kff, Qu, Quuk, scal, nrs, njl, ncs, trace, votes, arrive, total;
     __host__ __device__ static IkLayout make(int T) {
         IkLayout l; l.T = T;
         long o = 0;
@@ -56,7 +69,7 @@ struct IkLayout {
         l.xs = take((long)(T + 1) * kNX); l.us = take((long)T * kNV);
         l.xs_try = take((long)kTrySlots * (T + 1) * kNX); l.us_try = take((long)kTrySlots * T * kNV);
         l.fs = take((long)(T + 1) * kNDX); l.xnext = take((long)T * kNX);
-        l.Lx = take((long)(T + 1) * kNDX); l.Lxx = take((long)(T + 1) * kNDX * kNDX);
+        l.Lx = take((long)(T + 1) * kNDX); l.Lqq = take((long)(T + 1) * kLqqDoubles); l.Hn = take((long)(T + 1) * kHnDoubles);
         l.Lu = take((long)T * kNV); l.Luu = take((long)T * kNV);
         l.A6 = take((long)T * 36); l.B6 = take((long)T * 36);
         l.K = take((long)T * kNV * kNDX); l.kff = take((long)T * kNV);

@@ -78,6 +78,19 @@ __device__ __forceinline__ void lds_read_row36(unsigned addr, double (&x)[36]) {
                  : "v"(addr) : "memory");
     _Pragma("unroll") for (int i = 0; i < 18; ++i) { x[2 * i] = t[i].x; x[2 * i + 1] = t[i].y; }
 }
+// 36 consecutive doubles of a row of its own per lane, as 36 single ds_read_b64 (two batches of 18).  Against lds_read_row36's
+// ds_read2_b64: that instruction is banked over 32 banks in groups of 16 lanes, so rows r and r + 16 collide whatever the (odd)
+// leading dimension -- and the Riccati wave's lanes 36..53 shadow rows 18..35 beside lanes 32..35's rows 32..35 (4 conflict cycles
+// per instruction, tools/lds_conflict_probe.hip); ds_read_b64 is banked over 64 banks in groups of 32 lanes, where those rows are
+// distinct (the shadow of a row in the same group reads the same address: a broadcast).
+__device__ __forceinline__ void lds_read_row36_b64(unsigned addr, double (&x)[36]) {
+    asm volatile("ds_read_b64 %0, %18 offset:0\n\t" "ds_read_b64 %1, %18 offset:8\n\t" "ds_read_b64 %2, %18 offset:16\n\t" "ds_read_b64 %3, %18 offset:24\n\t" "ds_read_b64 %4, %18 offset:32\n\t" "ds_read_b64 %5, %18 offset:40\n\t" "ds_read_b64 %6, %18 offset:48\n\t" "ds_read_b64 %7, %18 offset:56\n\t" "ds_read_b64 %8, %18 offset:64\n\t" "ds_read_b64 %9, %18 offset:72\n\t" "ds_read_b64 %10, %18 offset:80\n\t" "ds_read_b64 %11, %18 offset:88\n\t" "ds_read_b64 %12, %18 offset:96\n\t" "ds_read_b64 %13, %18 offset:104\n\t" "ds_read_b64 %14, %18 offset:112\n\t" "ds_read_b64 %15, %18 offset:120\n\t" "ds_read_b64 %16, %18 offset:128\n\t" "ds_read_b64 %17, %18 offset:136\n\t" "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]), "=&v"(x[8]), "=&v"(x[9]), "=&v"(x[10]), "=&v"(x[11]), "=&v"(x[12]), "=&v"(x[13]), "=&v"(x[14]), "=&v"(x[15]), "=&v"(x[16]), "=&v"(x[17])
+                 : "v"(addr) : "memory");
+    asm volatile("ds_read_b64 %0, %18 offset:144\n\t" "ds_read_b64 %1, %18 offset:152\n\t" "ds_read_b64 %2, %18 offset:160\n\t" "ds_read_b64 %3, %18 offset:168\n\t" "ds_read_b64 %4, %18 offset:176\n\t" "ds_read_b64 %5, %18 offset:184\n\t" "ds_read_b64 %6, %18 offset:192\n\t" "ds_read_b64 %7, %18 offset:200\n\t" "ds_read_b64 %8, %18 offset:208\n\t" "ds_read_b64 %9, %18 offset:216\n\t" "ds_read_b64 %10, %18 offset:224\n\t" "ds_read_b64 %11, %18 offset:232\n\t" "ds_read_b64 %12, %18 offset:240\n\t" "ds_read_b64 %13, %18 offset:248\n\t" "ds_read_b64 %14, %18 offset:256\n\t" "ds_read_b64 %15, %18 offset:264\n\t" "ds_read_b64 %16, %18 offset:272\n\t" "ds_read_b64 %17, %18 offset:280\n\t" "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(x[18]), "=&v"(x[19]), "=&v"(x[20]), "=&v"(x[21]), "=&v"(x[22]), "=&v"(x[23]), "=&v"(x[24]), "=&v"(x[25]), "=&v"(x[26]), "=&v"(x[27]), "=&v"(x[28]), "=&v"(x[29]), "=&v"(x[30]), "=&v"(x[31]), "=&v"(x[32]), "=&v"(x[33]), "=&v"(x[34]), "=&v"(x[35])
+                 : "v"(addr) : "memory");
+}
 // 36 doubles at a stride of 37 doubles (a column of a row-major 36 x 37 staging matrix): two batches of 18 ds_read_b64
 __device__ __forceinline__ void lds_read_col36_ld37(unsigned addr, double (&x)[36]) {
     asm volatile("ds_read_b64 %0, %18 offset:0\n\tds_read_b64 %1, %18 offset:296\n\tds_read_b64 %2, %18 offset:592\n\tds_read_b64 %3, %18 offset:888\n\tds_read_b64 %4, %18 offset:1184\n\tds_read_b64 %5, %18 offset:1480\n\tds_read_b64 %6, %18 offset:1776\n\tds_read_b64 %7, %18 offset:2072\n\tds_read_b64 %8, %18 offset:2368\n\tds_read_b64 %9, %18 offset:2664\n\tds_read_b64 %10, %18 offset:2960\n\tds_read_b64 %11, %18 offset:3256\n\tds_read_b64 %12, %18 offset:3552\n\tds_read_b64 %13, %18 offset:3848\n\tds_read_b64 %14, %18 offset:4144\n\tds_read_b64 %15, %18 offset:4440\n\tds_read_b64 %16, %18 offset:4736\n\tds_read_b64 %17, %18 offset:5032\n\t" "s_waitcnt lgkmcnt(0)"

@@ -36,7 +36,7 @@ class KinoDynDeviceBatch:
         self.ws_doubles = lib.bmpc_ik_workspace_doubles(T)
         off = (C.c_long * 8)()
         lib.bmpc_ik_layout(T, off)
-        self.off = dict(zip(("xs", "us", "scal", "K", "k", "fs", "Lx", "Lxx"), list(off)))
+        self.off = dict(zip(("xs", "us", "scal", "K", "k", "fs", "Lx", "Lqq"), list(off)))
         t_off, t_it, t_w = C.c_long(0), C.c_int(0), C.c_int(0)
         lib.bmpc_ik_layout_trace(T, C.byref(t_off), C.byref(t_it), C.byref(t_w))
         self.trace_off, self.trace_iters, self.trace_width = t_off.value, t_it.value, t_w.value

@@ -264,7 +264,7 @@ typedef struct {
 int bmpc_ik_batch_struct_size(void);     /* sizeof(bmpc_ik_batch_t), to catch binding drift */
 long bmpc_ik_active_list_ints(long B);   /* length of bmpc_ik_batch_t.active_list */
 int bmpc_ik_workspace_doubles(int n_col);
-void bmpc_ik_layout(int n_col, long *offsets8);      /* xs, us, scalars, K, k, fs, Lx, Lxx */
+void bmpc_ik_layout(int n_col, long *offsets8);      /* xs, us, scalars, K, k, fs, Lx, Lqq (the q-block of L_xx in MFMA tile layout) */
 /* telemetry: rows [iteration i < *iters][*width = 4] at *offset of a problem's workspace: cost, regularisation, accepted step
  * length (0 = none) and stopping criterion |Q_u|^2 as SolverDDP holds them at the end of iteration i */
 void bmpc_ik_layout_trace(int n_col, long *offset, int *iters, int *width);
