@@ -275,7 +275,9 @@ NOTES = {
 def summary(out):
     """The numbers a reader of the line's tail needs, flat and last: per KinoDyn leg ms per batch solve, speed-up over the CPU port
     on all host cores and the dominant kernel; the batch-1 latencies."""
-    s = {"headline_ms_per_step": out.get("ms_per_step"), "headline_speedup_vs_cpu_all_cores": out.get("speedup_vs_cpu_all_cores"),
+    s = {"headline_ms_per_step": out.get("ms_per_step"), "headline_solves_per_s": out.get("value"),
+         "batch_6144_solves_per_s": out.get("batch_6144", {}).get("value") if isinstance(out.get("batch_6144"), dict) else None,
+         "headline_speedup_vs_cpu_all_cores": out.get("speedup_vs_cpu_all_cores"),
          "headline_speedup_vs_matrix_free_cpu": out.get("speedup_vs_matrix_free_cpu"), "p50_latency_ms_batch1": out.get("p50_latency_ms_batch1")}
     for key, short in (("kinodyn_full_solve", "kinodyn_solo12"), ("kinodyn_go2_h60", "kinodyn_go2_h60"), ("kinodyn_n100", "kinodyn_n100")):
         leg = out.get(key)
@@ -471,6 +473,7 @@ def biconvex_leg(D, args):
     last_kernel = bb._lib.lib().bmpc_biconvex_last_kernel_name().decode()
     last_kernel = {"biconvex_admm_kernel": "biconvex_admm_kernel<double>"}.get(last_kernel, last_kernel)
     prec = {"f64": "fp64", "f32": "fp32 iterates, fp64 decisions"}[args.precision]
+    lpp = int(bb._lib.lib().bmpc_biconvex_last_lanes_per_problem())
     out = {
         "metric": "MPC solves/sec (batch, whole node), %s, %d ADMM iters, %s" % (METRIC_SHAPE.get(args.config, args.config), args.admm_iters, prec),
         "value": total / elapsed, "unit": "solves/s", "n_gpus": W, "steps": args.steps,
@@ -482,7 +485,7 @@ def biconvex_leg(D, args):
                    "global_batch": B * W, "parallelism": "batch-shard x%d" % W},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": last_kernel, "kernel_ms": kern_ms,
+                     "kernel": last_kernel, "lanes_per_problem": lpp, "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_launch": abytes,
                      "valu": {"model_flops_per_launch": flops,
                               "achieved_tflops": flops / (kern_ms * 1e-3) / 1e12,
@@ -491,6 +494,20 @@ def biconvex_leg(D, args):
         "diverged": int(counts[0]), "fista_iters_per_solve": counts[1] / (B * W),
     }
     return out, pb
+
+
+def other_batch_size_leg(D, args, B):
+    """Informational: the same kernel at a batch size where three problems per wave save a round of waves (bmpc_set_three_per_wave:
+    B = 6144 is 2048 waves of three = two rounds over the 1024 SIMDs, 3072 waves of two would be three)"""
+    import torch
+    from bunmpc_amd import batch as bb
+    from bunmpc_amd import problems
+    pb = problems.make_batch(args.config, B, first=D.rank * B)
+    db = bb.DeviceBatch(pb, device=D.dev, num_iters=args.admm_iters, maxit=args.maxit, precision=args.precision)
+    dt = D.timed(db.solve, 10, 2) / 10
+    r = db.results()
+    return {"batch": B, "value": D.world * B / dt, "unit": "solves/s", "ms_per_step": dt * 1e3, "diverged": int((r["stats"][:, 5] != 0).sum()),
+            "lanes_per_problem": int(bb._lib.lib().bmpc_biconvex_last_lanes_per_problem())}
 
 
 def fp32_parity_note(pb, args):
@@ -668,6 +685,8 @@ def main():
             for _ in range(3):
                 bb.solve_host(pb, num_iters=args.admm_iters, maxit=args.maxit, precision=args.precision)
             return 3 * pb.B / (time.perf_counter() - th)
+        if args.config == "solo12_trot" and args.precision == "f64":
+            out["batch_6144"] = guarded(lambda: other_batch_size_leg(D, args, 6144))
         if world == 1 and not args.no_latency:
             lat = guarded(lambda: p50_latency(args.config, args.admm_iters))
             out["p50_latency_ms_batch1"] = lat.get("p50_ms", lat)

@@ -58,6 +58,14 @@ __global__ __launch_bounds__(64) void lane_selftest_kernel(const double *in, dou
     out[192 + i] = seg_sum<32>(v);
     out[256 + i] = seg_sum<64>(v);
     out[320 + i] = (double)__popcll(__ballot(v > 0.0));
+    out[384 + i] = seg_sum<21>(i < 63 ? v : 0.0);                                                    // every lane of a 21-lane segment
+    double a = i < 63 ? v : 0.0, b = i < 63 ? 2.0 * v : 0.0;
+    seg_sum2<21>(a, b);                                                                                // the designated lanes only
+    out[448 + i] = a;
+    out[512 + i] = b;
+    out[576 + i] = (double)seg_uniform<21>(__ballot(v > 40.0) & seg_desig<21>());                  // the spread masks, as a number (< 2^63: exact up to 2^53 -- compared by bits on the host through two halves)
+    out[640 + i] = (double)(unsigned)(seg_uniform<21>(__ballot(i == 16 || i == 48)) >> 32);
+    out[704 + i] = (double)(unsigned)(seg_uniform<21>(__ballot(i == 16 || i == 48)) & 0xffffffffu);
 }
 
 template <typename R, int LPP, bool RAW, bool HASQF>
@@ -74,8 +82,8 @@ hipError_t launch(const BatchArgs &a, hipStream_t stream) {
 template <int LPP>
 hipError_t launch_lpp(const BatchArgs &a, hipStream_t stream) {
     if (a.precision == 1) {   // fp32 arithmetic: harness form only
-        if (a.raw) return hipErrorInvalidValue;
-        return launch<float, LPP, false, false>(a, stream);
+        if (a.raw || LPP == 21) return hipErrorInvalidValue;
+        return launch<float, LPP == 21 ? 32 : LPP, false, false>(a, stream);
     }
     if (!a.raw) return launch<double, LPP, false, false>(a, stream);
     return a.qf ? launch<double, LPP, true, true>(a, stream) : launch<double, LPP, true, false>(a, stream);
@@ -83,12 +91,38 @@ hipError_t launch_lpp(const BatchArgs &a, hipStream_t stream) {
 
 }  // namespace
 
+// Horizons of 17..21 knots: 0 = 32-lane segments (two problems per wave), 1 = 21-lane segments (three per wave), 2 (default) = whichever
+// finishes the batch sooner.  The kernel runs one wave per SIMD; a wave of three problems takes ~8 % longer than a wave of two
+// (the segment sums cost more), so three per wave wins whenever it needs fewer ROUNDS of waves over the chip's SIMDs -- at
+// B = 4096 on an MI355X (1024 SIMDs) both need two rounds, 1366 waves or 2048, and two per wave is the faster one; at B = 3072 or
+// 6144 three per wave saves a whole round (1.41e6 solves/s against 1.03e6) -- or when the waves' run times differ widely anyway
+// (num_iters well above ten: the ADMM's early exit, biconvex.cpp:111-114, makes the iteration counts differ per problem and the
+// scheduler backfills; measured at num_iters = 100, B = 4096: 31 -> 28 ms).  (Tried and dropped: B = 4096 as one round of three per
+// wave for 3072 problems + the one-problem-per-wave kernel for the other 1024 -- 2.29 + 1.7 ms, level with 2 x 2.02 ms.)
+static int g_three_per_wave = 2;
+int set_three_per_wave(int on) { const int old = g_three_per_wave; g_three_per_wave = on; return old; }
+static long chip_simds() {
+    static int simds = 0;
+    if (simds == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        simds = 4 * cus;
+    }
+    return simds;
+}
+static bool three_per_wave_pays(const BatchArgs &a) {
+    if (g_three_per_wave != 2) return g_three_per_wave != 0;
+    const long simds = chip_simds(), w3 = (a.B + 2) / 3, w2 = (a.B + 1) / 2;
+    return (w3 + simds - 1) / simds < (w2 + simds - 1) / simds || a.c.num_iters >= 25;
+}
 static int g_latency_max_batch = 1024;
 int set_latency_mapping_max_batch(int max_batch) { const int old = g_latency_max_batch; g_latency_max_batch = max_batch; return old; }
 static int g_exact_step_decisions = 0;
 int set_exact_step_decisions(int on) { const int old = g_exact_step_decisions; g_exact_step_decisions = on; return old; }
 // which kernel the calling host thread's latest launch_biconvex_admm took (tests of the default dispatch; profiles)
 static thread_local const char *t_last_kernel = "";
+static thread_local int t_last_lpp = 0;       // lanes per problem of that launch (0: the one-problem-per-wave kernel)
+int biconvex_last_lanes_per_problem() { return t_last_lpp; }
 const char *biconvex_last_kernel_name() { return t_last_kernel; }
 
 hipError_t launch_biconvex_admm(const BatchArgs &a, int n_eff, hipStream_t stream) {
@@ -102,13 +136,17 @@ hipError_t launch_biconvex_admm(const BatchArgs &a, int n_eff, hipStream_t strea
     // few problems, short horizon: one problem per wave (the chain of a solve is ~2.3x shorter; biconvex_latency.hip)
     if (a.B <= g_latency_max_batch && latency_mapping_fits(a, n_eff)) {
         t_last_kernel = "biconvex_latency_kernel";
+        t_last_lpp = 0;
         BatchArgs al = a;
         al.exact_step_decisions = g_exact_step_decisions;
         return launch_biconvex_latency(al, stream);
     }
     const int k = a.H + 1;
     t_last_kernel = a.precision == 1 ? "biconvex_admm_kernel_f32" : "biconvex_admm_kernel";
-    if (k <= 16) return launch_lpp<16>(a, stream);
+    if (k <= 16) { t_last_lpp = 16; return launch_lpp<16>(a, stream); }
+    // 17..21 knots (the headline shape): three problems per wave in 21-lane segments (fp64; the fp32 kernels keep 32-lane segments)
+    if (k <= 21 && k > 16 && a.precision == 0 && three_per_wave_pays(a)) { t_last_lpp = 21; return launch_lpp<21>(a, stream); }
+    t_last_lpp = k <= 32 ? 32 : 64;
     if (k <= 32) return launch_lpp<32>(a, stream);
     return launch_lpp<64>(a, stream);
 }
@@ -121,7 +159,7 @@ hipError_t launch_lane_selftest(const double *in, double *out, hipStream_t strea
 const char *biconvex_kernel_name(int H, int raw) {
     (void)raw;
     const int k = H + 1;
-    return k <= 16 ? "biconvex_admm_kernel<double, 16" : (k <= 32 ? "biconvex_admm_kernel<double, 32" : "biconvex_admm_kernel<double, 64");
+    return k <= 16 ? "biconvex_admm_kernel<double, 16" : (k <= 21 && g_three_per_wave == 1 ? "biconvex_admm_kernel<double, 21" : (k <= 32 ? "biconvex_admm_kernel<double, 32" : "biconvex_admm_kernel<double, 64"));
 }
 
 }  // namespace bunmpc

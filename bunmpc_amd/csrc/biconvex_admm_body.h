@@ -29,7 +29,7 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
     const int seg = lane / LPP;
     const int H = a.H;
     const long prob = (long)blockIdx.x * (64 / LPP) + seg;
-    const bool pvalid = prob < a.B;
+    const bool pvalid = seg < 64 / LPP && prob < a.B;      // (LPP = 21: lane 63 belongs to no segment)
     const bool kvalid = pvalid && t <= H;  // owns knot t (X block t)
     const bool rvalid = pvalid && t < H;   // owns dynamics row-block t and force block t
     const bool l0 = pvalid && t == 0;      // also owns the x_init rows 9H..9H+8
@@ -243,12 +243,14 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
                     const double Lh = (double)L_f * 0.5, rhs = Lh * g2s;
                     mask_t bt = __ballot(cvs > rhs);
                     done = __ballot(g2s < tol2);
-                    const mask_t edge = __ballot((fabs(cvs - rhs) <= 1e-14 * rhs) || (fabs(g2s - tol2) <= 1e-14 * tol2));
+                    const mask_t edge = __ballot((fabs(cvs - rhs) <= 1e-14 * rhs) || (fabs(g2s - tol2) <= 1e-14 * tol2)) & seg_desig<LPP>();
                     if (edge != 0) {
                         const double Gn = sqrt(g2s);
                         bt = __ballot(cvs > Lh * (Gn * Gn));
                         done = __ballot(Gn < tol);
                     }
+                    bt = seg_uniform<LPP>(bt);      // (LPP = 21: the sums live at three lanes; their decisions go to their segments)
+                    done = seg_uniform<LPP>(done);
                     bt &= pend;
                     pend = bt;
                     if (bt == 0) break;
@@ -406,12 +408,14 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
                     const double Lh = (double)L_x * 0.5, rhs = Lh * g2s;   // see the force loop for the sqrt-free form
                     mask_t bt = __ballot(cvs > rhs);
                     done = __ballot(g2s < tol2);
-                    const mask_t edge = __ballot((fabs(cvs - rhs) <= 1e-14 * rhs) || (fabs(g2s - tol2) <= 1e-14 * tol2));
+                    const mask_t edge = __ballot((fabs(cvs - rhs) <= 1e-14 * rhs) || (fabs(g2s - tol2) <= 1e-14 * tol2)) & seg_desig<LPP>();
                     if (edge != 0) {
                         const double Gn = sqrt(g2s);
                         bt = __ballot(cvs > Lh * (Gn * Gn));
                         done = __ballot(Gn < tol);
                     }
+                    bt = seg_uniform<LPP>(bt);      // (LPP = 21: the sums live at three lanes; their decisions go to their segments)
+                    done = seg_uniform<LPP>(done);
                     bt &= pend;
                     pend = bt;
                     if (bt == 0) break;

@@ -63,6 +63,8 @@ hipError_t launch_biconvex_admm(const BatchArgs &a, int n_eff, hipStream_t strea
 bool latency_mapping_fits(const BatchArgs &a, int n_eff);
 hipError_t launch_biconvex_latency(const BatchArgs &a, hipStream_t stream);
 int set_latency_mapping_max_batch(int max_batch);   // returns the old value
+int set_three_per_wave(int mode);                    // 21-lane segments for 17..21 knots: 0 never, 1 always, 2 when it pays (default); returns the old value
+int biconvex_last_lanes_per_problem();               // of the calling host thread's latest launch: 16 / 21 / 32 / 64, 0 = one problem per wave
 int set_exact_step_decisions(int on);                // ... takes every step decision from the fp64 sums; returns the old value
 
 // fp32 instantiations (biconvex_admm_f32.hip); called by launch_biconvex_admm with the lanes per problem (16 / 32 / 64), the grid
@@ -72,7 +74,7 @@ hipError_t launch_biconvex_admm_f32(const BatchArgs &a, int lpp, unsigned grid, 
 int biconvex_admm_f32_scratch_bytes();    // private-segment bytes per lane of the fp32 kernels (hipFuncGetAttributes), -1 on error
 
 // Lane-exchange self test (DPP shifts and segment sums used by the kernel).
-// out must hold 6*64 doubles.
+// out must hold 12*64 doubles.
 hipError_t launch_lane_selftest(const double *in, double *out, hipStream_t stream);
 
 // Name of the kernel symbol for a given H (for profiling / bench reports).

@@ -43,10 +43,66 @@ __device__ __forceinline__ double swap32_sum(double v) {
     return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
 }
 
+// ---- LPP = 21: THREE problems per wave for horizons of 17..21 knots (the headline shape, H = 20: with 32-lane segments 22 of the
+// 64 lanes own no knot).  Segments are the lane ranges 0..20, 21..41, 42..62 (lane 63 idle); the neighbour exchanges (wave
+// shifts by one lane) do not care where a segment ends, the segment SUMS do: 21 lanes are not a butterfly's power of two and
+// every segment straddles two DPP rows of 16 lanes.  Each row holds lanes of at most two segments -- the one that CONTINUES
+// into the next row (part P of the row; all of row 0) and the one that came from the previous row (part Q; all of row 3).  The
+// two parts are summed within the row by the usual four-stage butterfly (both at once), row_bcast:15 carries P to the next
+// row, and P(row k-1) + Q(row k) is the sum of segment k-1: every lane of row k holds it, so it is read at lanes 16 / 32 / 48 (the
+// first lanes of rows 1 / 2 / 3: `seg_desig`).  The decisions of a FISTA step are lane masks anyway: they are taken at those three
+// lanes and spread over their segments by scalar bit operations (`seg_uniform`).  Fixed order of additions; a lane's value never
+// meets another segment's (selects, not multiplications by 0 / 1: a diverged problem's NaNs stay its own).
+constexpr int DPP_ROW_BCAST15 = 0x142;  // lane 15 of each row -> every lane of the next row (gfx9)
+__device__ __forceinline__ double dpp_bcast15(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, DPP_ROW_BCAST15, 0xe, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, DPP_ROW_BCAST15, 0xe, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ bool seg21_is_p(int lane) { const int row = lane >> 4; return row == 0 || lane / 21 == (16 * row) / 21 + 1; }
+constexpr mask_t kSeg21Desig = (1ull << 16) | (1ull << 32) | (1ull << 48);
+constexpr mask_t kSeg21Lanes[3] = {(1ull << 21) - 1, ((1ull << 21) - 1) << 21, ((1ull << 21) - 1) << 42};
+// the sums of a and b over the 21-lane segments; valid at the designated lanes (16, 32, 48) only
+__device__ __forceinline__ void seg21_sum2(double &a, double &b, bool is_p) {
+    double pa = is_p ? a : 0.0, pb = is_p ? b : 0.0;
+    double qa = is_p ? 0.0 : a, qb = is_p ? 0.0 : b;        // (selects: a - pa would turn a diverged problem's NaN into a NaN of the other part)
+    double t0, t1, t2, t3;
+    t0 = dpp_mov<DPP_QUAD_XOR1>(pa); t1 = dpp_mov<DPP_QUAD_XOR1>(qa); t2 = dpp_mov<DPP_QUAD_XOR1>(pb); t3 = dpp_mov<DPP_QUAD_XOR1>(qb);
+    pa += t0; qa += t1; pb += t2; qb += t3;
+    t0 = dpp_mov<DPP_QUAD_XOR2>(pa); t1 = dpp_mov<DPP_QUAD_XOR2>(qa); t2 = dpp_mov<DPP_QUAD_XOR2>(pb); t3 = dpp_mov<DPP_QUAD_XOR2>(qb);
+    pa += t0; qa += t1; pb += t2; qb += t3;
+    t0 = dpp_mov<DPP_ROW_HALF_MIRROR>(pa); t1 = dpp_mov<DPP_ROW_HALF_MIRROR>(qa); t2 = dpp_mov<DPP_ROW_HALF_MIRROR>(pb); t3 = dpp_mov<DPP_ROW_HALF_MIRROR>(qb);
+    pa += t0; qa += t1; pb += t2; qb += t3;
+    t0 = dpp_mov<DPP_ROW_MIRROR>(pa); t1 = dpp_mov<DPP_ROW_MIRROR>(qa); t2 = dpp_mov<DPP_ROW_MIRROR>(pb); t3 = dpp_mov<DPP_ROW_MIRROR>(qb);
+    pa += t0; qa += t1; pb += t2; qb += t3;
+    a = dpp_bcast15(pa) + qa;
+    b = dpp_bcast15(pb) + qb;
+}
+// value of v at lane `src` (compile-time constant), wave-uniform
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+// ... the sum of v over the lane's segment in EVERY lane of it (per ADMM iteration, not per FISTA iteration: three readlanes)
+__device__ __forceinline__ double seg21_sum(double v, int lane) {
+    double z = 0.0;
+    seg21_sum2(v, z, seg21_is_p(lane));
+    const double s0 = lane_bcast(v, 16), s1 = lane_bcast(v, 32), s2 = lane_bcast(v, 48);
+    return lane < 21 ? s0 : (lane < 42 ? s1 : s2);
+}
+// a mask whose bits at the designated lanes say what each segment decided -> that decision on every lane of the segment
+__device__ __forceinline__ mask_t seg21_spread(mask_t m) {
+    return ((m >> 16) & 1 ? kSeg21Lanes[0] : 0ull) | ((m >> 32) & 1 ? kSeg21Lanes[1] : 0ull) | ((m >> 48) & 1 ? kSeg21Lanes[2] : 0ull);
+}
+// lanes whose segment sums (seg_sum2) are meaningful; a decision mask made segment-uniform
+template <int LPP> __device__ __forceinline__ mask_t seg_desig() { return LPP == 21 ? kSeg21Desig : ~mask_t(0); }
+template <int LPP> __device__ __forceinline__ mask_t seg_uniform(mask_t m) { return LPP == 21 ? seg21_spread(m) : m; }
+
 // Sum over the LPP-lane segment, result in every lane of it (fixed butterfly order,
 // so all lanes hold the same bits).
 template <int LPP>
 __device__ __forceinline__ double seg_sum(double v) {
+    if (LPP == 21) return seg21_sum(v, (int)(threadIdx.x & 63));
     v += dpp_mov<DPP_QUAD_XOR1>(v);
     v += dpp_mov<DPP_QUAD_XOR2>(v);
     v += dpp_mov<DPP_ROW_HALF_MIRROR>(v);
@@ -61,6 +117,7 @@ __device__ __forceinline__ double seg_sum(double v) {
 // side by side each hides the other's waits.  Same order of additions per sum as seg_sum, hence the same bits.
 template <int LPP>
 __device__ __forceinline__ void seg_sum2(double &a, double &b) {
+    if (LPP == 21) { seg21_sum2(a, b, seg21_is_p((int)(threadIdx.x & 63))); return; }    // (valid at seg_desig<21>() only)
     double ta, tb;
     ta = dpp_mov<DPP_QUAD_XOR1>(a); tb = dpp_mov<DPP_QUAD_XOR1>(b); a += ta; b += tb;
     ta = dpp_mov<DPP_QUAD_XOR2>(a); tb = dpp_mov<DPP_QUAD_XOR2>(b); a += ta; b += tb;

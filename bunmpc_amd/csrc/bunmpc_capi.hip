@@ -140,6 +140,8 @@ extern "C" {
 
 int bmpc_abi_version(void) { return 2; }
 int bmpc_batch_struct_size(void) { return (int)sizeof(bmpc_batch_t); }
+int bmpc_set_three_per_wave(int mode) { return bunmpc::set_three_per_wave(mode); }
+int bmpc_biconvex_last_lanes_per_problem(void) { return bunmpc::biconvex_last_lanes_per_problem(); }
 int bmpc_set_latency_mapping_max_batch(int max_batch) { return bunmpc::set_latency_mapping_max_batch(max_batch); }
 int bmpc_set_exact_step_decisions(int on) { return bunmpc::set_exact_step_decisions(on); }
 int bmpc_biconvex_fp32_scratch_bytes(void) { return bunmpc::biconvex_admm_f32_scratch_bytes(); }
@@ -157,7 +159,7 @@ int bmpc_set_device(int device) {
 }
 
 int bmpc_selftest_lanes(void) {
-    double in[64], out[6 * 64];
+    double in[64], out[12 * 64];
     for (int i = 0; i < 64; ++i) in[i] = (double)(i + 1) + 0.25 * (i % 3);
     DevBuf b;
     HIP_TRY(b.ensure(sizeof(in) + sizeof(out)));
@@ -180,6 +182,26 @@ int bmpc_selftest_lanes(void) {
                 return fail(BMPC_DEVICE_ERROR, "seg_sum<" + std::to_string(lpp) + "> not segment-uniform");
         }
         if (out[320 + i] != 64.0) return fail(BMPC_DEVICE_ERROR, "ballot popcount mismatch");
+    }
+    // the 21-lane segments (three problems per wave): sums in every lane of a segment, at the designated lanes, and the spread of
+    // a decision taken there
+    double s21[3] = {0, 0, 0};
+    for (int i = 0; i < 63; ++i) s21[i / 21] += in[i];
+    for (int i = 0; i < 63; ++i) {
+        if (!near(out[384 + i], s21[i / 21])) return fail(BMPC_DEVICE_ERROR, "seg_sum<21> mismatch at lane " + std::to_string(i));
+        if (out[384 + i] != out[384 + (i / 21) * 21]) return fail(BMPC_DEVICE_ERROR, "seg_sum<21> not segment-uniform");
+    }
+    for (int sgm = 0; sgm < 3; ++sgm) {
+        const int d = 16 * (sgm + 1);
+        if (!near(out[448 + d], s21[sgm]) || !near(out[512 + d], 2.0 * s21[sgm])) return fail(BMPC_DEVICE_ERROR, "seg_sum2<21> mismatch at its designated lane");
+        if (out[448 + d] != out[384 + 21 * sgm]) return fail(BMPC_DEVICE_ERROR, "seg_sum2<21> and seg_sum<21> differ");
+    }
+    {   // in[i] > 40 at lanes 16 (no), 32 (no: 33.5), 48 (yes: 49) -> only segment 2; lanes 16 and 48 set -> segments 0 and 2
+        const unsigned long long seg0 = (1ull << 21) - 1, seg2 = seg0 << 42;
+        if (out[576] != (double)seg2) return fail(BMPC_DEVICE_ERROR, "seg_uniform<21> (one segment) mismatch");
+        const unsigned long long want = seg0 | seg2;
+        if (out[640] != (double)(unsigned)(want >> 32) || out[704] != (double)(unsigned)(want & 0xffffffffu))
+            return fail(BMPC_DEVICE_ERROR, "seg_uniform<21> (two segments) mismatch");
     }
     return BMPC_OK;
 }

@@ -50,6 +50,9 @@ using namespace rbd;
 #ifdef BWD_PROFILE
 #define PSTAMP(k) { const long long now_ = __builtin_readcyclecounter(); pc[k] += now_ - pt0; pt0 = now_; }
 #define PSTAMPV(k, x) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(x) :: "memory"); PSTAMP(k) asm volatile("" : "+v"(x) :: "memory"); }
+#elif defined(BWD_MARK)
+#define PSTAMP(k)
+#define PSTAMPV(k, x) asm volatile("; BWDMARK " #k ::: "memory");
 #else
 #define PSTAMP(k)
 #define PSTAMPV(k, x)
@@ -657,6 +660,17 @@ __device__ __forceinline__ void lds_read_mfma_acc_upper(unsigned base, double (&
                  : "v"(base) : "memory");
 }
 
+#ifndef BWD_WPE
+#define BWD_WPE 1      // waves per SIMD the one-wave Riccati kernel is compiled for (2 = the 256-register build)
+#endif
+constexpr bool kBwdLean = BWD_WPE == 2;
+// lean build: nothing moves across a phase boundary of the node (hipcc otherwise stretches the phases over each other -- the staged
+// row of G stays in registers through the elimination, the tiles' operands are fetched during the back substitution, ...)
+#define LEAN_FENCE if (NWB == 1 && kBwdLean) __builtin_amdgcn_sched_barrier(0);     // the one-wave kernel's low-register variant (same arithmetic, fewer values alive at once)
+// a wave-uniform double moved to scalar registers
+__device__ __forceinline__ double uni_d(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 // value of v in lane `src` (compile-time constant), wave-uniform: two v_readlane_b32
 __device__ __forceinline__ double lane_value(double v, int src) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
@@ -678,23 +692,48 @@ __device__ __forceinline__ double rcp64(double b) {
 // What a lane needs of node t's compact L_xx (IkLayout: Lqq tiles, Hn) for its elements of the six upper MFMA tiles: 18 loads,
 // each wave instruction over contiguous bytes (the full row it replaces: 36 loads with a 288-byte lane stride).
 struct LxxLane { double lq[9], mb[6], w, d11, d22; };
-__device__ __forceinline__ void lxx_lane_load(const double *ws, const IkLayout &L, int t, int lane, LxxLane &o) {
+// element of a global array addressed as a WAVE-UNIFORM base (scalar registers) + a 32-bit per-lane byte offset: `global_load v,
+// v_off, s[base:base+1] offset:imm`.  Written as `ws + L.x + t * n + lane` the address is a 64-bit per-lane sum, and the Riccati
+// node keeps some twenty such pointer pairs alive (or, in the 256-register build, reloads them from scratch at every use).
+__device__ __forceinline__ const double *at_u(const double *ubase, unsigned byte_off) {
+    return reinterpret_cast<const double *>(reinterpret_cast<const char *>(ubase) + byte_off);
+}
+__device__ __forceinline__ double *at_u(double *ubase, unsigned byte_off) {
+    return reinterpret_cast<double *>(reinterpret_cast<char *>(ubase) + byte_off);
+}
+// the per-lane byte offsets of lxx_lane_load (node-independent: computed once per pass)
+struct LxxOffsets { unsigned t00, t01, t11, m0, m1, m02, m12, d11, d22; };
+__device__ __forceinline__ LxxOffsets lxx_offsets(int lane) {
+    const unsigned li = lane & 15, lk = lane >> 4, c = li < 2 ? li : 0;
+    LxxOffsets o;
+    o.t00 = 8u * (unsigned)lane;                                  // Lqq[v * 64 + lane]
+    o.t01 = 8u * (256u + lk * 2u + c);                            // Lqq[256 + (v * 4 + lk) * 2 + c]
+    o.t11 = 8u * (288u + (lk & 1u) * 2u + c);
+    // M[k = 4 ks + lk][j = 16 J + li]: every lane loads an existing element (what is not its own becomes zero after the load)
+    o.m0 = 8u * (lk * (unsigned)kNDX + li);                       // ks = 0, J = 0, 1 (+ 16 J in the immediate)
+    o.m02 = li < 4 ? 8u * (lk * (unsigned)kNDX + 32u + li) : 0u;  // ks = 0, J = 2
+    o.m1 = lk < 2 ? 8u * ((4u + lk) * (unsigned)kNDX + li) : 0u;  // ks = 1, J = 0, 1
+    o.m12 = lk < 2 && li < 4 ? 8u * ((4u + lk) * (unsigned)kNDX + 32u + li) : 0u;
+    o.d11 = 8u * ((unsigned)kHnD11 + li);
+    o.d22 = 8u * ((unsigned)kHnD22 + (li & 3u));
+    return o;
+}
+// wsu: the problem's workspace (wave-uniform)
+__device__ __forceinline__ void lxx_lane_load(const double *wsu, const IkLayout &L, int t, int lane, const LxxOffsets &f, LxxLane &o) {
     const int li = lane & 15, lk = lane >> 4;
-    const double *Lqq = ws + L.Lqq + (long)t * kLqqDoubles, *Hn = ws + L.Hn + (long)t * kHnDoubles;
-    UNROLL_RBD for (int v = 0; v < 4; ++v) o.lq[v] = Lqq[v * 64 + lane];
-    const int c = li < 2 ? li : 0;          // (every lane loads an existing element; what is not its own is replaced by zero)
-    UNROLL_RBD for (int v = 0; v < 4; ++v) { const double x = Lqq[256 + (v * 4 + lk) * 2 + c]; o.lq[4 + v] = li < 2 ? x : 0.0; }
-    { const double x = Lqq[288 + (lk & 1) * 2 + c]; o.lq[8] = li < 2 && lk < 2 ? x : 0.0; }
-    UNROLL_RBD for (int ks = 0; ks < 2; ++ks)
-        UNROLL_RBD for (int J = 0; J < 3; ++J) {
-            const int k = 4 * ks + lk, j = 16 * J + li;
-            const bool ok = k < 6 && j < kNDX;
-            const double x = Hn[(ok ? k : 0) * kNDX + (ok ? j : 0)];
-            o.mb[3 * ks + J] = ok ? x : 0.0;
-        }
+    const double *Lqq = wsu + L.Lqq + (long)t * kLqqDoubles, *Hn = wsu + L.Hn + (long)t * kHnDoubles;
+    UNROLL_RBD for (int v = 0; v < 4; ++v) o.lq[v] = at_u(Lqq, f.t00)[v * 64];
+    UNROLL_RBD for (int v = 0; v < 4; ++v) { const double x = at_u(Lqq, f.t01)[v * 8]; o.lq[4 + v] = li < 2 ? x : 0.0; }
+    { const double x = *at_u(Lqq, f.t11); o.lq[8] = li < 2 && lk < 2 ? x : 0.0; }
+    {
+        const double x00 = at_u(Hn, f.m0)[0], x01 = at_u(Hn, f.m0)[16], x02 = *at_u(Hn, f.m02);
+        const double x10 = at_u(Hn, f.m1)[0], x11 = at_u(Hn, f.m1)[16], x12 = *at_u(Hn, f.m12);
+        o.mb[0] = x00; o.mb[1] = x01; o.mb[2] = li < 4 ? x02 : 0.0;
+        o.mb[3] = lk < 2 ? x10 : 0.0; o.mb[4] = lk < 2 ? x11 : 0.0; o.mb[5] = lk < 2 && li < 4 ? x12 : 0.0;
+    }
     o.w = Hn[kHnW];
-    o.d11 = Hn[kHnD11 + li];
-    { const double x = Hn[kHnD22 + (li & 3)]; o.d22 = li < 4 ? x : 0.0; }
+    o.d11 = *at_u(Hn, f.d11);
+    { const double x = *at_u(Hn, f.d22); o.d22 = li < 4 ? x : 0.0; }
 }
 // acc (the six tiles on and above the block diagonal, numbered as in the Schur update) += L_xx of the node
 __device__ __forceinline__ void lxx_add_tiles(mfma_acc_t (&acc)[6], const LxxLane &x, int lane) {
@@ -888,7 +927,7 @@ __device__ __forceinline__ void backward_gains_wave(BackwardLds<2> &s, double *w
 template <int NWB, bool FUSED>
 __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b, BackwardLds<NWB> &s, int lane, FusedCtl *ctl, Ticker &tk) {
     const IkLayout L = IkLayout::make(a.T);
-    double *ws = a.ws + b * L.total;
+    double *ws = a.ws + uni(b) * L.total;      // (scalar registers: the base of every workspace access of the pass)
     double *sc = ws + L.scal;
     const int T = a.T;
     bool feas = sc[S_FEAS] != 0.0;
@@ -947,6 +986,7 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
     const int uq = ul ? lane - kNV : 0;
     const unsigned row_addr = lds_offset(s.N + r * LD), col_addr = lds_offset(s.N + r);
     const unsigned a6_addr = lds_offset(s.A6), b6_addr = lds_offset(s.B6), fs_addr = lds_offset(s.fs);
+    const LxxOffsets lxo = lxx_offsets(lane);
     double d1, d2, st;
 #ifdef BWD_PROFILE
     long long pc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pt0;
@@ -957,7 +997,7 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
         double m[kNDX];   // the one 36-wide register row: V -> N -> G -> V_xx -> V
         {   // V_T = L_xx(T) + xreg I, put together in the tile layout its compact form is made for and read back by rows
             LxxLane lt;
-            lxx_lane_load(ws, L, T, lane, lt);
+            lxx_lane_load(ws, L, T, lane, lxo, lt);
             mfma_acc_t acc[6];
             UNROLL_RBD for (int tl = 0; tl < 6; ++tl) acc[tl] = mfma_acc_t{0.0, 0.0, 0.0, 0.0};
             lxx_add_tiles(acc, lt, lane);
@@ -982,14 +1022,21 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
         // to arrive.  Loaded at the top of its own node the row had ~5K cycles before its first use and the small vectors none
         // (a global-memory latency exposed twice per node: 3.4K + 2.1K of 22.5K cycles, tools/bwd_profile.py).
         double lx_t, lu_t, luu_t, a6_t, b6_t, fs_t, dt;
+        const unsigned off_r = 8u * (unsigned)(row ? r : 0), off_u = 8u * (unsigned)uq, off_36 = 8u * (unsigned)(lane < 36 ? lane : 0),
+                       off_uu = 8u * (unsigned)(lane >= kNDX && lane < kNDX + kNV ? lane - kNDX : 0);
         auto fetch_node = [&](int t, double &o_lx, double &o_lu, double &o_luu, double &o_a6, double &o_b6, double &o_fs, double &o_dt) {
+            // (uniform base + 32-bit lane offset, every lane an existing element: unconditional loads, zero selected afterwards)
             o_dt = a.dt[b * T + t];
-            o_lx = row ? ws[L.Lx + (long)t * kNDX + r] : 0.0;
-            o_lu = ul ? ws[L.Lu + (long)t * kNV + uq] : 0.0;
-            o_luu = lane >= kNDX && lane < kNDX + kNV ? ws[L.Luu + (long)t * kNV + lane - kNDX] : 0.0;   // on the lane of Q_uu row p
-            o_a6 = lane < 36 ? ws[L.A6 + (long)t * 36 + lane] : 0.0;
-            o_b6 = lane < 36 ? ws[L.B6 + (long)t * 36 + lane] : 0.0;
-            o_fs = row ? ws[L.fs + (long)t * kNDX + r] : 0.0;
+            const double xlx = *at_u(ws + L.Lx + (long)t * kNDX, off_r), xlu = *at_u(ws + L.Lu + (long)t * kNV, off_u);
+            const double xluu = *at_u(ws + L.Luu + (long)t * kNV, off_uu);
+            const double xa6 = *at_u(ws + L.A6 + (long)t * 36, off_36), xb6 = *at_u(ws + L.B6 + (long)t * 36, off_36);
+            const double xfs = *at_u(ws + L.fs + (long)t * kNDX, off_r);
+            o_lx = row ? xlx : 0.0;
+            o_lu = ul ? xlu : 0.0;
+            o_luu = lane >= kNDX && lane < kNDX + kNV ? xluu : 0.0;   // on the lane of Q_uu row p
+            o_a6 = lane < 36 ? xa6 : 0.0;
+            o_b6 = lane < 36 ? xb6 : 0.0;
+            o_fs = row ? xfs : 0.0;
         };
         bool have = false;      // node t's small reads were requested a node ahead
         for (int t = T - 1; t >= 0; --t) {
@@ -1005,20 +1052,21 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
             if (row) { s.Vx[r] = vx; s.fs[r] = fs_t; }
             const double dt_t = dt;      // (this node's; the variables above are about to be overwritten by the requests for node t - 1)
             double nlx = 0.0, nlu = 0.0, nluu = 0.0, na6 = 0.0, nb6 = 0.0, nfs = 0.0, ndt = 0.0;
-            const bool next_there = t > 0 && (!FUSED || lds_flag(ctl->ready[t - 1]) == ctl->stamp);
+            // (lean build: no request a node ahead -- its fourteen registers live through the whole node; the SIMD's other wave covers the wait)
+            const bool next_there = !(NWB == 1 && kBwdLean) && t > 0 && (!FUSED || lds_flag(ctl->ready[t - 1]) == ctl->stamp);
             if (next_there) fetch_node(t - 1, nlx, nlu, nluu, na6, nb6, nfs, ndt);
             // the node's compact L_xx: requested here, used at the very end of the node (the Schur update) -- the whole node to arrive
             LxxLane lxx;
-            lxx_lane_load(ws, L, t, lane, lxx);
+            if (!(NWB == 1 && kBwdLean)) lxx_lane_load(ws, L, t, lane, lxo, lxx);
             wave_sync();
-            PSTAMPV(0, m[0])
+            PSTAMPV(0, m[0]) LEAN_FENCE
             apply_FxT(m, a6_addr, b6_addr, dt_t);                  // column r of N = F_x^T V
             if (row) { UNROLL_RBD for (int i = 0; i < kNDX; ++i) s.N[i * LD + r] = m[i]; }
             wave_sync();
-            PSTAMPV(1, m[0])
+            PSTAMPV(1, m[0]) LEAN_FENCE
             lds_read_row36_b64(row_addr, m);                         // row r of N
             apply_FxT(m, a6_addr, b6_addr, dt_t);                  // row r of G = N F_x
-            PSTAMPV(2, m[35])
+            PSTAMPV(2, m[35]) LEAN_FENCE
             // Q_x = L_x + F_x^T V_x ;  Q_u = L_u + dt (F_x^T V_x)[v]
             double fvx;
             if (r < 6) { fvx = 0.0; UNROLL_RBD for (int c = 0; c < 6; ++c) fvx += s.A6[6 * c + r] * s.Vx[c]; }
@@ -1042,7 +1090,7 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
             }
             const double dgv = urow ? luu_t + xreg : 0.0;                // L_uu + reg of control p on lane 36 + p
             if (row) { UNROLL_RBD for (int j = 0; j < kNDX; ++j) s.N[r * LD + j] = m[j]; }       // row of G -> LDS (L_xx joins it in the tiles)
-            PSTAMPV(3, al[17])
+            PSTAMPV(3, al[17]) LEAN_FENCE
             // Pivots and the column entries every lane needs travel by v_readlane (wave-uniform, no LDS, no waiting).  A
             // non-positive or NaN pivot fails the pass (Eigen::LLT info != Success).
             // One reciprocal square root per pivot serves both uses (1 / piv = rs^2 for the elimination, rs for the scaling of the
@@ -1051,27 +1099,29 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
             double idg[kNV];
             double rs, mydg = 0.0;
             const int buf = NWB == 2 ? (hand & 1) : 0;      // the hand-over buffer of this node
+            int badpiv = 0;      // (an integer OR per pivot: as `bad = bad || ...` hipcc kept all eighteen pivots for one late evaluation -- in scratch, in the 256-register build)
             {
                 const double piv = lane_value(al[0], kNDX) + lane_value(dgv, kNDX);
-                if (!(piv > 0.0)) bad = true;
+                badpiv |= piv > 0.0 ? 0 : 1; asm volatile("" : "+v"(badpiv));       // (taken NOW: left to itself hipcc keeps the pivots and compares at the node's end)
                 rs = rsqrt64(piv);
             }
             UNROLL_RBD for (int j = 0; j < kNV; ++j) {
-                idg[j] = rs;
-                if (NWB == 2) mydg = lane == kNDX + j ? rs : mydg;      // 1 / L[j][j] stays on the lane of row j (one select, no branch)
+                if (!(NWB == 1 && kBwdLean)) idg[j] = rs;
+                if (NWB == 2 || kBwdLean) mydg = lane == kNDX + j ? rs : mydg;      // 1 / L[j][j] stays on the lane of row j (one select, no branch)
                 const double f = al[j] * (rs * rs);
                 double rs_next = 0.0;
                 if (j + 1 < kNV) {
                     al[j + 1] -= f * lane_value(al[j], kNDX + j + 1);
                     const double piv = lane_value(al[j + 1], kNDX + j + 1) + lane_value(dgv, kNDX + j + 1);
-                    if (!(piv > 0.0)) bad = true;
+                    badpiv |= piv > 0.0 ? 0 : 1; asm volatile("" : "+v"(badpiv));       // (taken NOW: left to itself hipcc keeps the pivots and compares at the node's end)
                     rs_next = rsqrt64(piv);
                 }
                 UNROLL_RBD for (int q = j + 2; q < kNV; ++q) al[q] -= f * lane_value(al[j], kNDX + q);
                 al[j] *= rs;                            // L[p][j] (rows p > j) / Y^T[r][j] / y_u[j]
                 rs = rs_next;
             }
-            PSTAMPV(4, idg[17])
+            bad = bad || badpiv != 0;
+            PSTAMPV(4, idg[17]) LEAN_FENCE
             // The factor goes to LDS once (packed by columns): the back substitutions read it back by broadcast -- one
             // ds_read_b128 per two entries instead of four v_readlane.
             if (urow) {      // row p of L (its p entries left of the diagonal) is at hand on lane 36 + p: packed by rows
@@ -1103,6 +1153,10 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
                 if (lane == 0) { s.tnode[buf] = t; if (FUSED) ctl->hand_count = hand + 1; }
             } else {
                 if (row) { UNROLL_RBD for (int p = 0; p < kNV; ++p) s.Ys[buf][r * LDK + p] = y[p]; }
+                if (kBwdLean) {      // the reciprocal pivots and Q_u wait in LDS (as for the gains wave of the two-wave kernel), not in registers
+                    if (urow) s.idg[0][lane - kNDX] = mydg;
+                    if (ul) s.qu[0][uq] = qu;
+                }
                 improvement_and_vx();
             }
             wave_sync();
@@ -1115,6 +1169,25 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
             if (NWB == 1) {   // back substitution L^T k = y, column by column: once k_p is final its multiples leave all earlier equations --
                 // independent updates (the row form accumulated each k_p through a chain of dependent FMAs)
                 const unsigned lc_addr = lds_offset(s.Lc[0]);
+                if (kBwdLean) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    lxx_lane_load(ws, L, t, lane, lxo, lxx);      // (lean: requested here, a back substitution ahead of the Schur update)
+                    double2_t lb[9];                        // the factor in batches of 18 entries
+                    int cur = -1;
+                    {
+                        double2_t dg[9];
+                        lds_read_b128x9(lds_offset(s.idg[0]), dg);
+                        UNROLL_RBD for (int p = 0; p < kNV; ++p) idg[p] = (p & 1) ? dg[p >> 1].y : dg[p >> 1].x;
+                    }
+                    UNROLL_RBD for (int p = kNV - 1; p >= 0; --p) {
+                        y[p] *= idg[p];
+                        UNROLL_RBD for (int q = p - 1; q >= 0; --q) {
+                            const int idx = p * (p - 1) / 2 + q, bb = idx / 18, e = idx % 18;
+                            if (bb != cur) { lds_read_b128x9(lc_addr + (unsigned)bb * 144, lb); cur = bb; }
+                            y[q] -= ((e & 1) ? lb[e >> 1].y : lb[e >> 1].x) * y[p];
+                        }
+                    }
+                } else {
                 double2_t lb[18];
                 int cur = -1;
                 UNROLL_RBD for (int p = kNV - 1; p >= 0; --p) {
@@ -1125,18 +1198,24 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
                         y[q] -= ((e & 1) ? lb[e >> 1].y : lb[e >> 1].x) * y[p];
                     }
                 }
+                }
                 // The gains leave the wave HERE, before the Schur update: this kernel runs two waves per SIMD (256 registers), the
                 // other wave fills the matrix pipe's shadow, and y / Q_u are dead by the time the six accumulator tiles are live.
+                if (kBwdLean) {
+                    double2_t qv[9];
+                    lds_read_b128x9(lds_offset(s.qu[0]), qv);
+                    UNROLL_RBD for (int p = 0; p < kNV; ++p) quv[p] = (p & 1) ? qv[p >> 1].y : qv[p >> 1].x;
+                }
                 UNROLL_RBD for (int p = 0; p < kNV; ++p) { d1 += quv[p] * y[p]; st += quv[p] * quv[p]; }   // d1 = Qu.k, stop = |Qu|^2
                 if (row) {      // (the empty asm keeps the stores in program order: clustered, hipcc spills a hundred registers around them)
-                    double *Kg = ws + L.K + (long)t * kNV * kNDX + r;
+                    double *Kg = at_u(ws + L.K + (long)t * kNV * kNDX, off_r);
                     UNROLL_RBD for (int p = 0; p < kNV; ++p) { Kg[p * kNDX] = y[p]; asm volatile("" ::: "memory"); }
                 } else if (lane == kQuLane) {
                     UNROLL_RBD for (int p = 0; p < kNV; ++p) ws[L.kff + (long)t * kNV + p] = y[p];
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            PSTAMPV(5, vx)
+            PSTAMPV(5, vx) LEAN_FENCE
             const int li = lane & 15, lk = lane >> 4;
             mfma_acc_t acc[6];
             {
@@ -1158,10 +1237,10 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
                 if (FUSED) tick_lds(tk); else bwd_barrier();
                 ++hand;
             }
-            PSTAMPV(6, vx)
+            PSTAMPV(6, vx) LEAN_FENCE
             tiles_to_rows(s.N, acc, xreg, lane);
             wave_sync();
-            PSTAMPV(7, vx)
+            PSTAMPV(7, vx) LEAN_FENCE
             lds_read_row36_b64(row_addr, m);
             {
                 double col[kNDX], chk = 0.0;
@@ -1181,7 +1260,7 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
             bad = bad || !(fabs(vx) < INFINITY);       // raiseIfNaN on Vx / Vxx
             bad = __any(bad && (row || lane < kNV));
             wave_sync();
-            PSTAMPV(8, vx)
+            PSTAMPV(8, vx) LEAN_FENCE
             have = next_there;
             if (next_there) {     // the node requested at the top becomes the current one
                 lx_t = nlx; lu_t = nlu; luu_t = nluu; a6_t = na6; b6_t = nb6; fs_t = nfs; dt = ndt;
@@ -1230,9 +1309,7 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
     } else if (lane == kQuLane) { sc[S_D1] = d1; sc[S_D2] = d2; sc[S_STOP] = st; }   // the lane of the feed-forward terms
 }
 
-#ifndef BWD_WPE
-#define BWD_WPE 1      // waves per SIMD the Riccati kernel is compiled for (2 = a 256-register build, an experiment switch)
-#endif
+
 template <int NWB>
 __global__ __launch_bounds__(64 * NWB, NWB == 1 ? BWD_WPE : 1) void ik_backward_kernel(const IkBatchArgs a) {
     __shared__ BackwardLds<NWB> s;

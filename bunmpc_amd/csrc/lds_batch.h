@@ -28,6 +28,12 @@ __device__ __forceinline__ void lds_read_b128x8(unsigned addr, double2_t (&o)[8]
                  : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
                  : "v"(addr) : "memory");
 }
+// 9 x 16 bytes (18 doubles) from a 16-byte aligned address
+__device__ __forceinline__ void lds_read_b128x9(unsigned addr, double2_t (&o)[9]) {
+    asm volatile("ds_read_b128 %0, %9 offset:0\n\t" "ds_read_b128 %1, %9 offset:16\n\t" "ds_read_b128 %2, %9 offset:32\n\t" "ds_read_b128 %3, %9 offset:48\n\t" "ds_read_b128 %4, %9 offset:64\n\t" "ds_read_b128 %5, %9 offset:80\n\t" "ds_read_b128 %6, %9 offset:96\n\t" "ds_read_b128 %7, %9 offset:112\n\t" "ds_read_b128 %8, %9 offset:128\n\t" "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8])
+                 : "v"(addr) : "memory");
+}
 // 11 x 16 bytes (22 doubles) from a 16-byte aligned address
 __device__ __forceinline__ void lds_read_b128x11(unsigned addr, double2_t (&o)[11]) {
     asm volatile("ds_read_b128 %0, %11 offset:0\n\tds_read_b128 %1, %11 offset:16\n\tds_read_b128 %2, %11 offset:32\n\tds_read_b128 %3, %11 offset:48\n\tds_read_b128 %4, %11 offset:64\n\tds_read_b128 %5, %11 offset:80\n\tds_read_b128 %6, %11 offset:96\n\tds_read_b128 %7, %11 offset:112\n\tds_read_b128 %8, %11 offset:128\n\tds_read_b128 %9, %11 offset:144\n\tds_read_b128 %10, %11 offset:160\n\t" "s_waitcnt lgkmcnt(0)"

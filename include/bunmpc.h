@@ -155,6 +155,14 @@ int bmpc_biconvex_solve_batch_host(const bmpc_batch_t *d);
  * chain of a solve is ~2.3x shorter), larger ones one knot per lane with 4 / 2 / 1 problems per wave.  Default 1024 (one
  * wave per SIMD of an MI355X); 0 = never.  Returns the old value. */
 int bmpc_set_latency_mapping_max_batch(int max_batch);
+/* Horizons of 17..21 knots (n_col = 16..20: the headline shape) in fp64 can run THREE problems per wave, in 21-lane segments,
+ * instead of two in 32-lane segments (same iterates; the segment sums behind the step decisions are added in another order, as
+ * between any two of the mappings).  mode 0: never, 1: always, 2 (default): when it finishes the batch sooner -- fewer rounds of
+ * waves over the chip's SIMDs (not at B = 4096 on an MI355X: 1366 waves or 2048, two rounds either way; at B = 3072 or 6144 it
+ * saves a round), or num_iters >= 25 (iteration counts differ per problem).  Returns the old value. */
+int bmpc_set_three_per_wave(int mode);
+/* lanes per problem of the calling host thread's latest batch solve: 16 / 21 / 32 / 64, 0 = the one-problem-per-wave kernel */
+int bmpc_biconvex_last_lanes_per_problem(void);
 /* The one-problem-per-wave kernel takes the two decisions of a FISTA step (retry, fista.cpp:16; exit, fista.cpp:29) from fp32
  * wave sums whenever both comparisons are clear of their thresholds by 1e-5 relative, from the fp64 sums and the reference
  * expression otherwise.  on = 1: always from the fp64 sums (a test switch: results must be bit-identical either way).

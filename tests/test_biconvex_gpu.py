@@ -215,16 +215,26 @@ def test_fp32_variant_on_a_ragged_batch():
         assert np.median(rel_l2(d32[k], d64[k])) < 1e-4 and rel_l2(d32[k], d64[k]).max() < 5e-3
 
 
-@pytest.mark.parametrize("which", ["batch", "wave"])
-def test_diverging_problem_does_not_poison_neighbours(oracle, mapping, which):
+@pytest.mark.parametrize("which", ["batch", "batch3", "wave"])
+def test_diverging_problem_does_not_poison_neighbours(oracle, hiplib, mapping, which):
     """NaN handling (biconvex.cpp:106-109): a problem that blows up reports status 2 and NaNs;
-    the problem sharing its wave is bit-for-bit what it is when solved without that neighbour."""
-    mapping(which)
+    the problems sharing its wave (one with 32-lane segments, two with 21-lane segments: "batch3") are bit-for-bit what they are
+    when solved without that neighbour."""
+    mapping("wave" if which == "wave" else "batch")
+    old3 = hiplib.bmpc_set_three_per_wave(1 if which == "batch3" else 0)
+    try:
+        _diverging_problem_body(oracle, hiplib, which)
+    finally:
+        hiplib.bmpc_set_three_per_wave(old3)
+
+
+def _diverging_problem_body(oracle, hiplib, which):
     b = problems.make_batch("solo12_trot", 4)
     bad = problems.make_batch("solo12_trot", 4)
     bad.x_init[1, 2] = 1e200                      # overflow -> inf/NaN in the first gradient
     bad.X_nom[1] = 1e200
     got = bb.solve_host(bad, num_iters=4)
+    assert hiplib.bmpc_biconvex_last_lanes_per_problem() == {"batch": 32, "batch3": 21, "wave": 0}[which]
     clean = bb.solve_host(b, num_iters=4)
     assert got["stats"][1, 5] == 2 and got["stats"][1, 0] == 1
     assert not np.isfinite(got["X"][1]).all()
@@ -272,6 +282,40 @@ def test_go2_at_the_references_mu_1_diverges_as_the_oracle(oracle, mapping, whic
     for k in "XFP":
         assert np.array_equal(got[k][free], calm[k][free]), k
     assert np.array_equal(got["stats"][free], calm["stats"][free]) and np.all(got["F"][free] == 0.0)
+
+
+@pytest.mark.parametrize("config,B,H,iters", [("solo12_trot", 100, None, 10), ("solo12_mixed", 31, None, 10), ("solo12_trot", 7, 16, 3),
+                                              ("solo12_trot", 64, 18, 4), ("go2_bound", 5, 20, 2)])
+def test_three_problems_per_wave_equal_two_per_wave(oracle, hiplib, mapping, config, B, H, iters):
+    """Horizons of 17..21 knots run three problems per wave in 21-lane segments (bmpc_set_three_per_wave, the default) instead of
+    two in 32-lane segments.  The iterates of a problem do not depend on the mapping: only the segment sums behind the step
+    decisions are added in another order, and wherever no decision sits within rounding of its threshold the two mappings leave
+    the SAME BITS -- all of X, F, P, the step constants, the history, every count.  Batch sizes that are no multiple of three,
+    partly filled last waves, per-problem weights (solo12_mixed), horizons below 21 knots (idle lanes inside the segments)."""
+    mapping("batch")
+    b = problems.make_batch(config, B, H=H) if H else problems.make_batch(config, B)
+    assert 17 <= b.H + 1 <= 21
+    out = {}
+    for on in (1, 0):
+        old = hiplib.bmpc_set_three_per_wave(on)
+        try:
+            out[on] = bb.solve_host(b, num_iters=iters, keep_hist=True)
+            assert hiplib.bmpc_biconvex_last_lanes_per_problem() == (21 if on else 32)
+        finally:
+            hiplib.bmpc_set_three_per_wave(old)
+    same = np.all(out[1]["trace"] == out[0]["trace"], axis=(1, 2))
+    print("%s B=%d H=%d: %d of %d problems on the same discrete path in both mappings" % (config, B, b.H, same.sum(), B))
+    assert same.mean() >= (0.6 if config == "solo12_mixed" else 0.9)      # (bound / pace: the chaotic regime, where any rounding difference flips counts)
+    for k in ("X", "F", "P", "L_x", "L_f"):
+        assert np.array_equal(out[1][k][same], out[0][k][same]), k
+    for k in ("hist", "dyn_viol"):      # (segment sums themselves: the same terms added in another order)
+        assert np.allclose(out[1][k][same], out[0][k][same], rtol=1e-12, atol=0, equal_nan=True), k
+    assert np.array_equal(out[1]["stats"][same], out[0]["stats"][same])
+    ref, spread = cpu_spread(b, iters, oracle, with_numpy=False)      # (chaotic problems: the measured envelope, tests/util.py)
+    err, bound = within_envelope(out[1], ref, spread)
+    assert np.all(err <= bound), (err, bound)
+    calm = spread <= 1e-9
+    assert np.array_equal(out[1]["stats"][calm], ref["stats"][calm])
 
 
 @pytest.mark.parametrize("which", ["batch", "wave"])
