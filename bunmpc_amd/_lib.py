@@ -186,6 +186,7 @@ _SIGS = {
     "bmpc_ik_set_fused_direct_max": (_I, [_I]),
     "bmpc_ik_set_express_near": (C.c_double, [C.c_double]),
     "bmpc_ik_batch_struct_size": (_I, []),
+    "bmpc_ik_kernel_occupancy": (None, [_P]),
     "bmpc_ik_active_list_ints": (C.c_long, [C.c_long]),
     "bmpc_ik_last_profile": (None, [_P]),
     "bmpc_ik_solve_batch_device": (_I, [_P, _P]),

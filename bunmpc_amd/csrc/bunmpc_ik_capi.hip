@@ -545,6 +545,7 @@ int bmpc_ik_set_blocking_waits(int on) { return g_blocking_waits.exchange(on != 
 int bmpc_ik_set_express_capacity(int n) { return g_express_cap.exchange(n); }
 int bmpc_ik_set_fused_direct_max(int n) { return g_fused_direct.exchange(n); }
 double bmpc_ik_set_express_near(double stop) { return g_express_near.exchange(stop); }
+void bmpc_ik_kernel_occupancy(int *out8) { bunmpc::ik_kernel_occupancy(out8); }
 int bmpc_ik_batch_struct_size(void) { return (int)sizeof(bmpc_ik_batch_t); }
 int bmpc_ik_set_speculative_below(int n_active) { return g_spec_line_search_below.exchange(n_active); }
 double bmpc_model_total_mass(const bmpc_model_t *m) { return m ? m->host.total_mass : 0.0; }

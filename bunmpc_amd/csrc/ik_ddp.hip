@@ -2192,6 +2192,19 @@ hipError_t ik_launch_calcdiff(const IkBatchArgs &a, hipStream_t st) {
     else hipLaunchKernelGGL(ik_calcdiff_kernel, dim3((unsigned)n), dim3(128), 0, st, a);
     return hipGetLastError();
 }
+// workgroups of each IK kernel one CU holds at once, as the runtime's occupancy query sees them (registers, LDS, wave slots):
+// {calcdiff (two waves per pair), calcdiff1 (one wave per pair), backward<1>, backward<2>, forward<1>, forward<2>, forward<3>, state}
+void ik_kernel_occupancy(int *out8) {
+    for (int i = 0; i < 8; ++i) out8[i] = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out8[0], ik_calcdiff_kernel, 128, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out8[1], ik_calcdiff1_kernel, 128, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out8[2], ik_backward_kernel<1>, 64, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out8[3], ik_backward_kernel<2>, 128, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out8[4], ik_forward_kernel<1>, 64, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out8[5], ik_forward_kernel<2>, 128, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out8[6], ik_forward_kernel<3>, 192, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out8[7], ik_state_kernel, 64, 0);
+}
 hipError_t ik_launch_backward(const IkBatchArgs &a, hipStream_t st) {
     if (a.bwd_waves == 2) hipLaunchKernelGGL(ik_backward_kernel<2>, dim3((unsigned)launch_problems(a)), dim3(128), 0, st, a);
     else hipLaunchKernelGGL(ik_backward_kernel<1>, dim3((unsigned)launch_problems(a)), dim3(64), 0, st, a);

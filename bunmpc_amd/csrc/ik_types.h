@@ -152,6 +152,7 @@ hipError_t ik_launch_com_mom(const RobotModelDev *model, const double *xs, doubl
 
 hipError_t ik_launch_state_ops_selftest(const double *x0, const double *x1, const double *dx, int n, double *dq, double *dr, double *iq, double *ir,
                                         hipStream_t s);
+void ik_kernel_occupancy(int *out8);      // workgroups per CU of the IK kernels (hipOccupancyMaxActiveBlocksPerMultiprocessor)
 hipError_t ik_launch_fill_refs(double *tasks, const double *X, double m, int B, int H, int T, hipStream_t s);
 
 }  // namespace bunmpc

@@ -270,6 +270,9 @@ typedef struct {
     bmpc_ik_sched_t sched;
 } bmpc_ik_batch_t;
 int bmpc_ik_batch_struct_size(void);     /* sizeof(bmpc_ik_batch_t), to catch binding drift */
+/* diagnostics: workgroups of each IK kernel a CU holds at once according to the runtime's occupancy query, in the order calcdiff
+ * (two waves per node pair), calcdiff1 (one wave per pair), backward<1>, backward<2>, forward<1>, forward<2>, forward<3>, state */
+void bmpc_ik_kernel_occupancy(int *out8);
 long bmpc_ik_active_list_ints(long B);   /* length of bmpc_ik_batch_t.active_list */
 int bmpc_ik_workspace_doubles(int n_col);
 void bmpc_ik_layout(int n_col, long *offsets8);      /* xs, us, scalars, K, k, fs, Lx, Lqq (the q-block of L_xx in MFMA tile layout) */
