@@ -5,7 +5,10 @@ sys.path.insert(0, ".")
 import numpy as np, torch
 from bunmpc_amd import problems, urdf_model
 from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
-import dataclasses
+from bunmpc_amd import _lib
+import dataclasses, os
+if os.environ.get("IK_FUSED_DIRECT"):       # 0: the lone problem through the lock-step kernels (two-wave Riccati kernel), not the fused one
+    _lib.lib().bmpc_ik_set_fused_direct_max(int(os.environ["IK_FUSED_DIRECT"]))
 robot = sys.argv[1] if len(sys.argv) > 1 else "solo12"      # solo12 (H = 20, H_ik = 10) | go2 (H = 60, H_ik = 30)
 model = urdf_model.RobotModel.from_json(open("bunmpc_amd/robots/%s.json" % robot).read())
 for B in ((1, 4096) if robot == "solo12" else (1, 1024)):
