@@ -86,6 +86,7 @@ _P = C.c_void_p
 _SIGS = {
     "bmpc_abi_version": (_I, []),
     "bmpc_set_three_per_wave": (_I, [_I]),
+    "bmpc_set_work_stealing": (_I, [_I]),
     "bmpc_biconvex_last_lanes_per_problem": (_I, []),
     "bmpc_batch_struct_size": (_I, []),
     "bmpc_set_latency_mapping_max_batch": (_I, [_I]),

@@ -35,6 +35,8 @@
 //     projections in fp32, while every decision the algorithm takes -- the backtracking test,
 //     both exit tests, the dynamics violation -- is reduced and compared in fp64.  HBM keeps fp64.
 #include "biconvex_kernels.h"
+#include <algorithm>
+#include <mutex>
 
 namespace bunmpc {
 namespace {
@@ -49,6 +51,8 @@ namespace {
 // this round's one-wave build it is level (4.11 vs 4.09 ms at B = 4096, 9.43 vs 9.30 ms on the Go2 shape).  Not taken.
 template <typename R, int LPP, int E, bool RAW, bool HASQF>
 __global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) { admm_body<R, LPP, E, RAW, HASQF>(a); }
+// the work-stealing variant (biconvex_admm_body.h: STEAL): three problems per wave, harness form, fp64
+__global__ __launch_bounds__(64) void biconvex_admm_steal_kernel(const BatchArgs a) { admm_body<double, 21, 4, false, false, true>(a); }
 __global__ __launch_bounds__(64) void lane_selftest_kernel(const double *in, double *out) {
     const int i = threadIdx.x;
     const double v = in[i];
@@ -76,6 +80,31 @@ hipError_t launch(const BatchArgs &a, hipStream_t stream) {
     const size_t lds = sizeof(R) * ((((size_t)a.c.maxit + 1) & ~(size_t)1) + per_wave * nstate);
     if (sizeof(R) == sizeof(float)) return launch_biconvex_admm_f32(a, LPP, grid, lds, stream);      // biconvex_admm_f32.hip
     hipLaunchKernelGGL((biconvex_admm_kernel<double, LPP, 4, RAW, HASQF>), dim3(grid), dim3(64), lds, stream, a);
+    return hipGetLastError();
+}
+
+// Device counters of the work-stealing launches: a ring of 64 per device, one per launch in flight (a launch zeroes its own on its
+// stream in front of the kernel; with 64 a counter comes round again only after 63 later launches of this process)
+int *steal_counter(hipStream_t stream) {
+    static std::mutex lock;
+    static int *ring[16] = {};
+    static unsigned next = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> hold(lock);
+    if (!ring[dev] && hipMalloc(reinterpret_cast<void **>(&ring[dev]), 64 * sizeof(int)) != hipSuccess) { ring[dev] = nullptr; return nullptr; }
+    int *c = ring[dev] + (next++ % 64);
+    if (hipMemsetAsync(c, 0, sizeof(int), stream) != hipSuccess) return nullptr;
+    return c;
+}
+// the persistent grid of the work-stealing kernel: one wave per SIMD is what its registers allow
+hipError_t launch_steal(const BatchArgs &a, long simds, hipStream_t stream) {
+    BatchArgs s = a;
+    s.queue = steal_counter(stream);
+    if (!s.queue) return hipErrorOutOfMemory;
+    const size_t nstate = 2 * 9 * (size_t)(a.H + 1) + 12 * (size_t)a.H;
+    const size_t lds = sizeof(double) * ((((size_t)a.c.maxit + 1) & ~(size_t)1) + 3 * nstate);
+    hipLaunchKernelGGL(biconvex_admm_steal_kernel, dim3((unsigned)simds), dim3(64), lds, stream, s);
     return hipGetLastError();
 }
 
@@ -115,6 +144,8 @@ static bool three_per_wave_pays(const BatchArgs &a) {
     const long simds = chip_simds(), w3 = (a.B + 2) / 3, w2 = (a.B + 1) / 2;
     return (w3 + simds - 1) / simds < (w2 + simds - 1) / simds || a.c.num_iters >= 25;
 }
+static int g_work_stealing = 1;       // 0: never the work-stealing kernel (tests: results must not depend on it)
+int set_work_stealing(int on) { const int old = g_work_stealing; g_work_stealing = on; return old; }
 static int g_latency_max_batch = 1024;
 int set_latency_mapping_max_batch(int max_batch) { const int old = g_latency_max_batch; g_latency_max_batch = max_batch; return old; }
 static int g_exact_step_decisions = 0;
@@ -145,7 +176,17 @@ hipError_t launch_biconvex_admm(const BatchArgs &a, int n_eff, hipStream_t strea
     t_last_kernel = a.precision == 1 ? "biconvex_admm_kernel_f32" : "biconvex_admm_kernel";
     if (k <= 16) { t_last_lpp = 16; return launch_lpp<16>(a, stream); }
     // 17..21 knots (the headline shape): three problems per wave in 21-lane segments (fp64; the fp32 kernels keep 32-lane segments)
-    if (k <= 21 && k > 16 && a.precision == 0 && three_per_wave_pays(a)) { t_last_lpp = 21; return launch_lpp<21>(a, stream); }
+    if (k <= 21 && k > 16 && a.precision == 0 && three_per_wave_pays(a)) {
+        t_last_lpp = 21;
+        // many ADMM iterations (the early exit makes the counts differ per problem) and more waves than the chip holds: segments that
+        // finish take the next problem (biconvex_admm_body.h: STEAL); the 32-bit offsets from the problem index must fit
+        const long S = chip_simds(), per = std::max<long>({(long)a.H * 128, 9L * (a.H + 1) * 8, a.sW_X * 8, a.sW_F * 8, a.sbounds * 8, (long)a.c.num_iters * 16});
+        if (g_work_stealing && !a.raw && a.c.num_iters >= 25 && (a.B + 2) / 3 > S && (double)a.B * (double)per < 2.0e9) {
+            t_last_kernel = "biconvex_admm_steal_kernel";
+            return launch_steal(a, S, stream);
+        }
+        return launch_lpp<21>(a, stream);
+    }
     t_last_lpp = k <= 32 ? 32 : 64;
     if (k <= 32) return launch_lpp<32>(a, stream);
     return launch_lpp<64>(a, stream);

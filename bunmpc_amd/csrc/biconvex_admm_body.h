@@ -18,7 +18,14 @@
 //     only; each wave tabulates them once in LDS.
 //   * a problem that finishes (|d| < tol or maxit) has its iterate latched into `fin` registers
 //     at that moment; the loop body itself carries no per-lane freeze selects.
-template <typename R, int LPP, int E, bool RAW, bool HASQF>
+//
+// STEAL (round 4; LPP = 21, many ADMM iterations): the grid is what the chip holds at once and a SEGMENT whose problem has finished
+// -- the ADMM's early exit (biconvex.cpp:111-114) makes the iteration counts differ per problem: 34 .. 100 at num_iters = 100 --
+// stores its results and takes the next unsolved problem from a device counter, instead of idling until the slowest problem of its
+// wave is done (a wave's time was the MAXIMUM over its three problems; the batch's now approaches the SUM over all problems / the
+// number of segments).  The arithmetic of a problem does not depend on which segment runs it, or when.  Addresses in this mode are
+// the arrays' own bases + 32-bit byte offsets from the problem index (the host checks that they fit).
+template <typename R, int LPP, int E, bool RAW, bool HASQF, bool STEAL = false>
 __device__ __forceinline__ void admm_body(const BatchArgs &a) {
     extern __shared__ double lds_raw[];
     R *cmtab = reinterpret_cast<R *>(lds_raw);   // [maxit]
@@ -28,13 +35,13 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
     const int t = lane % LPP;           // knot owned by this lane
     const int seg = lane / LPP;
     const int H = a.H;
-    const long prob = (long)blockIdx.x * (64 / LPP) + seg;
-    const bool pvalid = seg < 64 / LPP && prob < a.B;      // (LPP = 21: lane 63 belongs to no segment)
+    long prob = (long)blockIdx.x * (64 / LPP) + seg;      // (STEAL: the segment's FIRST problem)
+    // STEAL: the lane's place in its segment decides what it owns; whether the segment has a problem at all is the `alive` mask's business
+    const bool pvalid = seg < 64 / LPP && (STEAL || prob < a.B);      // (LPP = 21: lane 63 belongs to no segment)
     const bool kvalid = pvalid && t <= H;  // owns knot t (X block t)
     const bool rvalid = pvalid && t < H;   // owns dynamics row-block t and force block t
     const bool l0 = pvalid && t == 0;      // also owns the x_init rows 9H..9H+8
     const long nx = 9L * (H + 1), nf = (long)NF * H;
-    const long pb = pvalid ? prob : 0;
     const mask_t rvalid_m = __ballot(rvalid), kvalid_m = __ballot(kvalid);
 
     const R m = (R)a.c.m, rho = (R)a.c.rho, mu = (R)a.c.mu, beta = (R)a.c.beta;
@@ -58,14 +65,18 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
     // are unconditional -- straight-line code in which base + offset folds into the instruction, instead of some sixty
     // exec-masked blocks each needing the address as a 64-bit register pair -- and what a lane has no business with is
     // replaced by zero after the load (ldz).  Stores stay conditional.
-    const long wave0 = (long)blockIdx.x * (64 / LPP);
-    const unsigned sl = pvalid ? (unsigned)seg : 0u;
+    const long wave0 = STEAL ? 0L : (long)blockIdx.x * (64 / LPP);
+    unsigned sl = STEAL ? (unsigned)(pvalid && prob < a.B ? prob : 0) : (pvalid ? (unsigned)seg : 0u);      // STEAL: the problem index itself
     const unsigned tk = (unsigned)(t <= H ? t : H), tr = (unsigned)(t < H ? t : H - 1);
-    const unsigned oX = 8u * (sl * (unsigned)nx + 9u * tk);                  // X, P, Qx, qx, lbx, ubx: [B][9 (H + 1)]
-    const unsigned oPI = 8u * (sl * (unsigned)nx + 9u * (unsigned)H);
-    const unsigned oF = 8u * (sl * (unsigned)nf + (unsigned)NF * tr);        // F, Qf, qf: [B][3 E H]
-    const unsigned oK = 8u * (sl * (unsigned)H + tr);                        // dt: [B][H]; cnt_plan: E * 4 doubles per entry
-    const unsigned oP9 = 8u * 9u * sl;                                        // x_init, X_ter: [B][9]
+    unsigned oX, oPI, oF, oK, oP9;
+    auto set_offsets = [&]() {
+        oX = 8u * (sl * (unsigned)nx + 9u * tk);                  // X, P, Qx, qx, lbx, ubx: [B][9 (H + 1)]
+        oPI = 8u * (sl * (unsigned)nx + 9u * (unsigned)H);
+        oF = 8u * (sl * (unsigned)nf + (unsigned)NF * tr);        // F, Qf, qf: [B][3 E H]
+        oK = 8u * (sl * (unsigned)H + tr);                        // dt: [B][H]; cnt_plan: E * 4 doubles per entry
+        oP9 = 8u * 9u * sl;                                        // x_init, X_ter: [B][9]
+    };
+    set_offsets();
     double *const Xu = a.X + wave0 * nx, *const Fu = a.F + wave0 * nf, *const Pu = a.P + wave0 * nx;
     const double *const xinit_u = a.x_init + wave0 * 9;
 
@@ -79,32 +90,59 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
         __syncthreads();
     }
 
-    const R dt = ldz<R>(a.dt + wave0 * H, oK, 0, rvalid);
-    const R dtp = from_prev(dt);  // dt of knot t-1 (0 for t == 0: previous lane is a dead/terminal lane)
+    R dt = ldz<R>(a.dt + wave0 * H, oK, 0, rvalid);
+    R dtp = from_prev(dt);  // dt of knot t-1 (0 for t == 0: previous lane is a dead/terminal lane)
     const bool cold = a.cold_start != 0;      // 1: fresh solver object (iterates and step constants reset); 2: iterates only --
     const bool fresh_L = a.cold_start == 1;   // FISTA's L_ is set in the constructor and survives every optimize call (fista.hpp:52)
-    R L_x = (R)(fresh_L ? a.L0_x : *at(a.L_x + wave0, 8u * sl));
-    R L_f = (R)(fresh_L ? a.L0_f : *at(a.L_f + wave0, 8u * sl));
-    if (cold) {  // KinoDynMP::set_warm_starts (kino_dyn.cpp:83-99): X = tile(x_init), F = 0, P = 0
-        if (kvalid) { UNROLL for (int l = 0; l < 9; ++l) Xg[l] = (R)at(xinit_u, oP9)[l]; }
-        if (rvalid) {
-            UNROLL for (int j = 0; j < NF; ++j) Fg[j] = R(0);
-            UNROLL for (int l = 0; l < 9; ++l) Pg[l] = R(0);
-        }
-        if (l0) { UNROLL for (int l = 0; l < 9; ++l) PIg[l] = R(0); }
-    } else {     // set_warm_start_vars: bring the caller's iterates on chip
-        if (kvalid) { UNROLL for (int l = 0; l < 9; ++l) Xg[l] = (R)at(Xu, oX)[l]; }
-        if (rvalid) {
-            UNROLL for (int j = 0; j < NF; ++j) Fg[j] = (R)at(Fu, oF)[j];
-            UNROLL for (int l = 0; l < 9; ++l) Pg[l] = (R)at(Pu, oX)[l];
-        }
-        if (l0) { UNROLL for (int l = 0; l < 9; ++l) PIg[l] = (R)at(Pu, oPI)[l]; }
-    }
-    mask_t alive = __ballot(pvalid);
+    const double L0x = a.L0_x, L0f = a.L0_f;      // (locals: read through `a` inside the lambda below, the two arguments got a stack copy)
+    R L_x, L_f;
     int n_admm = 0, it_f = 0, it_x = 0, bt_f = 0, bt_x = 0, status = 0;
     double last_viol = 0.0;
+    // the problem `sl` names (every offset set) comes on chip: step constants, iterates, counters (lanes of the segments in m)
+    auto load_problem = [&](mask_t m) {
+        const bool on = lanes(m);
+        const R nLx = (R)(fresh_L ? L0x : *at(a.L_x + wave0, 8u * sl)), nLf = (R)(fresh_L ? L0f : *at(a.L_f + wave0, 8u * sl));
+        if (on) { L_x = nLx; L_f = nLf; n_admm = 0; it_f = 0; it_x = 0; bt_f = 0; bt_x = 0; status = 0; last_viol = 0.0; }
+        if (cold) {  // KinoDynMP::set_warm_starts (kino_dyn.cpp:83-99): X = tile(x_init), F = 0, P = 0
+            if (on && kvalid) { UNROLL for (int l = 0; l < 9; ++l) Xg[l] = (R)at(xinit_u, oP9)[l]; }
+            if (on && rvalid) {
+                UNROLL for (int j = 0; j < NF; ++j) Fg[j] = R(0);
+                UNROLL for (int l = 0; l < 9; ++l) Pg[l] = R(0);
+            }
+            if (on && l0) { UNROLL for (int l = 0; l < 9; ++l) PIg[l] = R(0); }
+        } else {     // set_warm_start_vars: bring the caller's iterates on chip
+            if (on && kvalid) { UNROLL for (int l = 0; l < 9; ++l) Xg[l] = (R)at(Xu, oX)[l]; }
+            if (on && rvalid) {
+                UNROLL for (int j = 0; j < NF; ++j) Fg[j] = (R)at(Fu, oF)[j];
+                UNROLL for (int l = 0; l < 9; ++l) Pg[l] = (R)at(Pu, oX)[l];
+            }
+            if (on && l0) { UNROLL for (int l = 0; l < 9; ++l) PIg[l] = (R)at(Pu, oPI)[l]; }
+        }
+    };
+    // ... and its results leave: one pass from LDS to the output blocks
+    auto store_problem = [&](mask_t m) {
+        const bool on = lanes(m);
+        if (on && kvalid) { UNROLL for (int l = 0; l < 9; ++l) at(Xu, oX)[l] = (double)Xg[l]; }
+        if (on && rvalid) {
+            UNROLL for (int j = 0; j < NF; ++j) at(Fu, oF)[j] = (double)Fg[j];
+            UNROLL for (int l = 0; l < 9; ++l) at(Pu, oX)[l] = (double)Pg[l];
+        }
+        if (on && l0) { UNROLL for (int l = 0; l < 9; ++l) at(Pu, oPI)[l] = (double)PIg[l]; }
+        if (on && l0) {
+            *at(a.L_x + wave0, 8u * sl) = (double)L_x;
+            *at(a.L_f + wave0, 8u * sl) = (double)L_f;
+            if (a.dyn_viol) *at(a.dyn_viol + wave0, 8u * sl) = last_viol;
+            if (a.stats) {
+                int *s = a.stats + (wave0 + sl) * kStats;
+                s[0] = n_admm; s[1] = it_f; s[2] = it_x; s[3] = bt_f; s[4] = bt_x; s[5] = status;
+            }
+        }
+    };
+    mask_t alive = __ballot(pvalid && prob < a.B);
+    L_x = (R)L0x; L_f = (R)L0f;      // (lanes of no problem: finite step constants, whatever they then compute is masked)
+    load_problem(alive);
 
-    for (int it = 0; it < a.c.num_iters; ++it) {
+    for (int it = 0; STEAL || it < a.c.num_iters; ++it) {
         if (alive == 0) break;
         // contact data of this knot: flags c_n, positions r_n  (centroidal.cpp:39-49); re-read in
         // each phase (L2-resident) rather than held in registers across the FISTA loops
@@ -464,32 +502,37 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
             const double nrm = sqrt(v2);
             if (lanes(alive)) {
                 last_viol = nrm;
+                const unsigned row = (unsigned)n_admm;      // the ADMM iteration this was, counted per problem (== it unless STEAL)
                 ++n_admm;
-                if (a.hist && l0) *at(a.hist + wave0 * a.c.num_iters, 8u * (sl * (unsigned)a.c.num_iters + (unsigned)it)) = nrm;
+                if (a.hist && l0) *at(a.hist + wave0 * a.c.num_iters, 8u * (sl * (unsigned)a.c.num_iters + row)) = nrm;
                 if (a.trace && l0) {
-                    int *tr = a.trace + ((wave0 + sl) * a.c.num_iters + it) * 4;
+                    int *tr = a.trace + ((wave0 + sl) * a.c.num_iters + row) * 4;
                     tr[0] = it_f; tr[1] = it_x; tr[2] = bt_f; tr[3] = bt_x;
                 }
                 if (isnan(nrm)) status = 2;                                   // biconvex.cpp:106-109
             }
-            alive &= ~__ballot(isnan(nrm) || nrm < exit_tol);                 // biconvex.cpp:106-109, 111-114
+            const mask_t ex = __ballot(isnan(nrm) || nrm < exit_tol);         // biconvex.cpp:106-109, 111-114
+            if (!STEAL) alive &= ~ex;
+            else {
+                // segments whose problem is over (exit, NaN, or all its iterations run): results out, the next problem in
+                const mask_t fin = alive & (ex | __ballot(n_admm >= a.c.num_iters));
+                if (fin != 0) {
+                    store_problem(fin);
+                    int np = -1;
+                    if (lanes(fin) && l0) np = (int)((long)gridDim.x * (64 / LPP)) + atomicAdd(a.queue, 1);
+                    static_assert(!STEAL || LPP == 21, "the segment broadcast below is written for three segments of 21 lanes");
+                    const int n0 = __builtin_amdgcn_readlane(np, 0), n1 = __builtin_amdgcn_readlane(np, 21), n2 = __builtin_amdgcn_readlane(np, 42);
+                    const int mine = seg == 0 ? n0 : (seg == 1 ? n1 : n2);
+                    const mask_t got = fin & __ballot(pvalid && mine >= 0 && mine < a.B);
+                    if (lanes(got)) { prob = mine; sl = (unsigned)mine; set_offsets(); }
+                    const R ndt = ldz<R>(a.dt, oK, 0, rvalid);
+                    if (lanes(got)) dt = ndt;
+                    dtp = from_prev(dt);
+                    load_problem(got);
+                    alive = (alive & ~fin) | got;
+                }
+            }
         }
     }
-
-    // ---- results: one pass from LDS to the output blocks
-    if (kvalid) { UNROLL for (int l = 0; l < 9; ++l) at(Xu, oX)[l] = (double)Xg[l]; }
-    if (rvalid) {
-        UNROLL for (int j = 0; j < NF; ++j) at(Fu, oF)[j] = (double)Fg[j];
-        UNROLL for (int l = 0; l < 9; ++l) at(Pu, oX)[l] = (double)Pg[l];
-    }
-    if (l0) { UNROLL for (int l = 0; l < 9; ++l) at(Pu, oPI)[l] = (double)PIg[l]; }
-    if (l0) {
-        *at(a.L_x + wave0, 8u * sl) = (double)L_x;
-        *at(a.L_f + wave0, 8u * sl) = (double)L_f;
-        if (a.dyn_viol) *at(a.dyn_viol + wave0, 8u * sl) = last_viol;
-        if (a.stats) {
-            int *s = a.stats + (wave0 + sl) * kStats;
-            s[0] = n_admm; s[1] = it_f; s[2] = it_x; s[3] = bt_f; s[4] = bt_x; s[5] = status;
-        }
-    }
+    if (!STEAL) store_problem(__ballot(pvalid));     // ---- results
 }

@@ -48,6 +48,7 @@ struct BatchArgs {
     double *dyn_viol, *hist;
     int *stats;
     int *trace;      // [B][num_iters][4] running totals {it_f, it_x, bt_f, bt_x} after every ADMM iteration, or null
+    int *queue;      // (set by the launcher) the work-stealing kernel's device counter: problems handed out beyond the first per segment
 };
 
 constexpr int kStats = 6;
@@ -64,6 +65,7 @@ bool latency_mapping_fits(const BatchArgs &a, int n_eff);
 hipError_t launch_biconvex_latency(const BatchArgs &a, hipStream_t stream);
 int set_latency_mapping_max_batch(int max_batch);   // returns the old value
 int set_three_per_wave(int mode);                    // 21-lane segments for 17..21 knots: 0 never, 1 always, 2 when it pays (default); returns the old value
+int set_work_stealing(int on);                       // the segment-level work-stealing kernel for num_iters >= 25 (default on); returns the old value
 int biconvex_last_lanes_per_problem();               // of the calling host thread's latest launch: 16 / 21 / 32 / 64, 0 = one problem per wave
 int set_exact_step_decisions(int on);                // ... takes every step decision from the fp64 sums; returns the old value
 

@@ -161,6 +161,12 @@ int bmpc_set_latency_mapping_max_batch(int max_batch);
  * waves over the chip's SIMDs (not at B = 4096 on an MI355X: 1366 waves or 2048, two rounds either way; at B = 3072 or 6144 it
  * saves a round), or num_iters >= 25 (iteration counts differ per problem).  Returns the old value. */
 int bmpc_set_three_per_wave(int mode);
+/* With many ADMM iterations (num_iters >= 25) the early exit (biconvex.cpp:111-114) makes the iteration counts differ per problem
+ * (34 .. 100 at the reference's num_iters = 100).  The three-per-wave kernel then runs as a PERSISTENT grid of one wave per SIMD in
+ * which a segment whose problem has finished stores its results and takes the next unsolved problem from a device counter
+ * ("biconvex_admm_steal_kernel"): the batch takes the sum of the problems' iterations over the segments, not the per-wave maxima.
+ * A problem's result does not depend on it.  on = 0: never (a test switch).  Default 1.  Returns the old value. */
+int bmpc_set_work_stealing(int on);
 /* lanes per problem of the calling host thread's latest batch solve: 16 / 21 / 32 / 64, 0 = the one-problem-per-wave kernel */
 int bmpc_biconvex_last_lanes_per_problem(void);
 /* The one-problem-per-wave kernel takes the two decisions of a FISTA step (retry, fista.cpp:16; exit, fista.cpp:29) from fp32

@@ -318,6 +318,39 @@ def test_three_problems_per_wave_equal_two_per_wave(oracle, hiplib, mapping, con
     assert np.array_equal(out[1]["stats"][calm], ref["stats"][calm])
 
 
+def test_work_stealing_does_not_change_results(hiplib):
+    """num_iters = 100 (the reference's own call): the ADMM's early exit makes the iteration counts differ per problem, and the
+    three-per-wave kernel runs as a persistent grid whose segments take the next unsolved problem when theirs has finished
+    (bmpc_set_work_stealing).  Which segment solves a problem, and when, must not show in ANY output: everything bit for bit as
+    from the plain three-per-wave launch -- iterates, step constants, counters, the per-iteration history.  B = 4099: more
+    problems than the chip's segments (so segments do take second problems) and no multiple of three."""
+    from bunmpc_amd import batch as bbm
+    B = 4099
+    b = problems.make_batch("solo12_trot", B)
+    out = {}
+    for on in (1, 0):
+        old = hiplib.bmpc_set_work_stealing(on)
+        try:
+            dev = bbm.DeviceBatch(b, num_iters=100, keep_hist=True)
+            dev.solve()
+            out[on] = dev.results()
+            name = hiplib.bmpc_biconvex_last_kernel_name().decode()
+            assert name == ("biconvex_admm_steal_kernel" if on else "biconvex_admm_kernel") and hiplib.bmpc_biconvex_last_lanes_per_problem() == 21
+            dev.solve()                      # a second launch: another counter of the ring, the same results
+            again = dev.results()
+            assert np.array_equal(again["X"], out[on]["X"]) and np.array_equal(again["stats"], out[on]["stats"])
+        finally:
+            hiplib.bmpc_set_work_stealing(old)
+    n = out[1]["stats"][:, 0]
+    print("work stealing: ADMM iterations min %d median %d max %d over %d problems" % (n.min(), np.median(n), n.max(), B))
+    assert n.min() < 60 and n.max() == 100 and np.all(out[1]["stats"][:, 5] == 0)
+    for k in ("X", "F", "P", "L_x", "L_f", "stats", "trace"):
+        assert np.array_equal(out[1][k], out[0][k]), k
+    # (the violation is a segment sum: its order of additions depends on WHICH of the wave's three segments holds the problem)
+    assert np.allclose(out[1]["dyn_viol"], out[0]["dyn_viol"], rtol=1e-12, atol=0)
+    assert np.allclose(out[1]["hist"], out[0]["hist"], rtol=1e-12, atol=0, equal_nan=True)
+
+
 @pytest.mark.parametrize("which", ["batch", "wave"])
 def test_early_exit_on_exit_tol(oracle, mapping, which):
     """||A_f X - b_f|| < exit_tol stops a problem (biconvex.cpp:111-114) while its wave-mate goes on."""
