@@ -222,7 +222,40 @@ struct alignas(16) CalcNode {         // per node of the workgroup
     double rs[kNDX];                  // state residual
     double cost_kin, cost_sc;         // node cost: momentum + CoM + frames | state + control
     double x[kNX + 1], u[kNV];
+    // The node's task block and its time step (terminal: 0), staged with the state in ONE coalesced load.  Read field by field
+    // from global memory -- `frame_w(f) != 0 ? frame_id(f) : -1`, the references, the weights: some sixty loads per node pair, each
+    // behind a condition or a call, each waited for on its own (`global_load ... s_waitcnt vmcnt(0)` sixty times in the ISA) -- they
+    // were what ik_calcdiff1 spent 61 % of its wave cycles waiting for.
+    double tk[kNodeTaskDoubles + 1];
 };
+// the one-step form (the fused kernel's producers: the two-step form there trips a back-end error of this hipcc, "Illegal instruction
+// detected: V_CMP_NE_U32_e32 0, $src_shared_base", where the LDS node is reached through a generic reference)
+__device__ __forceinline__ void calc_stage_simple(const IkBatchArgs &a, long b, int t, const double *ws, const IkLayout &L, CalcNode &q, int l) {
+    const int nn = a.T + 1;
+    if (l >= 0 && l < kNX) q.x[l] = ws[L.xs + (long)t * kNX + l];
+    if (l >= 0 && l < kNV) q.u[l] = t == a.T ? 0.0 : ws[L.us + (long)t * kNV + l];
+    if (l >= 0 && l < kNodeTaskDoubles) q.tk[l] = a.tasks[(b * nn + t) * kNodeTaskDoubles + l];
+    if (l == kNodeTaskDoubles) q.tk[l] = t == a.T ? 0.0 : a.dt[b * a.T + t];
+}
+// Stage node t of problem b into q: lane l < 38 takes one element of x, u and the task block each.  In two steps -- every load of
+// the node (of BOTH nodes of a pair, in the callers) is requested before the first LDS store waits for one: as `q.x[l] = ws[...]`
+// behind a lane condition each of the eight was a load, a wait and a store of its own.  (Every lane loads an existing element.)
+struct StagedNode { double x, u, tk, dt; };
+__device__ __forceinline__ StagedNode calc_stage_load(const IkBatchArgs &a, long b, int t, const double *ws, const IkLayout &L, int l) {
+    const int nn = a.T + 1, tu = t < a.T ? t : a.T - 1;
+    StagedNode v;
+    v.x = ws[L.xs + (long)t * kNX + (l < kNX ? l : 0)];
+    v.u = ws[L.us + (long)tu * kNV + (l < kNV ? l : 0)];
+    v.tk = a.tasks[(b * nn + t) * kNodeTaskDoubles + (l < kNodeTaskDoubles ? l : 0)];
+    v.dt = a.dt[b * a.T + tu];
+    return v;
+}
+__device__ __forceinline__ void calc_stage_store(const IkBatchArgs &a, int t, CalcNode &q, int l, const StagedNode &v) {
+    if (l < kNX) q.x[l] = v.x;
+    if (l < kNV) q.u[l] = t == a.T ? 0.0 : v.u;
+    if (l < kNodeTaskDoubles) q.tk[l] = v.tk;
+    if (l == kNodeTaskDoubles) q.tk[l] = t == a.T ? 0.0 : v.dt;
+}
 constexpr int kCalcNodes = 2;
 struct alignas(16) CalcLds { CalcNode nd[kCalcNodes]; RobotModelDev m; };
 
@@ -393,17 +426,27 @@ __device__ __forceinline__ void calc_columns(const RobotModelDev &m, CalcNode &q
 // (4) Gauss-Newton L_x / L_xx / L_u / L_uu / cost of node t from its LDS block, by ONE wave (all 64 lanes)
 __device__ __forceinline__ void calc_assemble(const IkBatchArgs &a, long b, int t, CalcNode &q, double *ws, const IkLayout &L, int lane,
                                               const double *state_w0, const double *ctrl_w0, double *cost_slot) {
-    const int nn = a.T + 1;
-    NodeTasks tk{a.tasks + (b * nn + t) * kNodeTaskDoubles};
+    NodeTasks tk{q.tk};
     const bool terminal = t == a.T;
-    const double dt = terminal ? 0.0 : a.dt[b * a.T + t];
+    const double dt = q.tk[kNodeTaskDoubles];
     const double wm = tk.mom_w(), wc = tk.com_w(), wst = tk.state_w(), wu = tk.ctrl_w();
-    const double *state_w = state_w0 + a.sn_state_w * t, *ctrl_w = ctrl_w0 + a.sn_ctrl_w * t;
+    // The weight vectors and the workspace through GLOBAL-address-space pointers (in the non-inlined instance the arguments come out
+    // of LDS and the pointers are generic: flat loads and stores, which count against the LDS counter too and were each waited for
+    // on their own), and every weight a lane needs requested here, in one batch, before anything waits.
+    typedef const double __attribute__((address_space(1))) *gcd_t;
+    typedef double __attribute__((address_space(1))) *gd_t;
+    const gcd_t state_w = (gcd_t)(state_w0 + a.sn_state_w * t), ctrl_w = (gcd_t)(ctrl_w0 + a.sn_ctrl_w * t);
+    const gd_t wsg = (gd_t)ws;
+    const int li_ = lane & 15;
+    double sw_k[6];
+    UNROLL_RBD for (int k = 0; k < 6; ++k) sw_k[k] = state_w[k];
+    const double sw_j = state_w[lane < kNDX ? lane : 0], sw_li = state_w[li_], sw_c = state_w[16 + (li_ < 2 ? li_ : 0)];
+    const double sw_t = state_w[16 + (lane < 20 ? lane : 0)], cw_i = ctrl_w[lane >= 40 && lane < 40 + kNV ? lane - 40 : 0];
     const double sc = terminal ? 1.0 : dt;
     if (!terminal && lane >= 40 && lane < 40 + kNV) {     // lanes the assembly leaves idle
         const int i = lane - 40;
-        ws[L.Lu + (long)t * kNV + i] = sc * wu * ctrl_w[i] * q.u[i];
-        ws[L.Luu + (long)t * kNV + i] = sc * wu * ctrl_w[i];
+        wsg[L.Lu + (long)t * kNV + i] = sc * wu * cw_i * q.u[i];
+        wsg[L.Luu + (long)t * kNV + i] = sc * wu * cw_i;
     }
     // node costs are summed by the backward pass: parked in the gap slot of this node (multi-kernel path) / in LDS (fused kernel)
     if (lane == 63) *cost_slot = terminal ? q.cost_kin + q.cost_sc : dt * (q.cost_kin + q.cost_sc);
@@ -417,7 +460,7 @@ __device__ __forceinline__ void calc_assemble(const IkBatchArgs &a, long b, int 
             UNROLL_RBD for (int k = 0; k < kRes; ++k) jw[k] = (k & 1) ? own[k >> 1].y : own[k >> 1].x;
         }
         {   // the momentum Jacobian M = d h_g / d (q, v), row-major, for the Riccati pass (IkLayout: kHnDoubles): lane j = column j
-            double *Hn = ws + L.Hn + (long)t * kHnDoubles;
+            const gd_t Hn = wsg + L.Hn + (long)t * kHnDoubles;
             UNROLL_RBD for (int k = 0; k < 6; ++k) Hn[k * kNDX + j] = jw[k];
         }
         UNROLL_RBD for (int k = 0; k < 6; ++k) jw[k] *= wm;
@@ -428,9 +471,9 @@ __device__ __forceinline__ void calc_assemble(const IkBatchArgs &a, long b, int 
         lds_read_b128x11(lds_offset(q.res), rr);
         double g = 0.0;
         UNROLL_RBD for (int k = 0; k < kRes; ++k) g += jw[k] * ((k & 1) ? rr[k >> 1].y : rr[k >> 1].x);
-        if (j < 6) { UNROLL_RBD for (int k = 0; k < 6; ++k) g += wst * state_w[k] * q.JlT[j][k] * q.rs[k]; }
-        else g += wst * state_w[j] * q.rs[j];
-        ws[L.Lx + (long)t * kNDX + j] = sc * g;
+        if (j < 6) { UNROLL_RBD for (int k = 0; k < 6; ++k) g += wst * sw_k[k] * q.JlT[j][k] * q.rs[k]; }
+        else g += wst * sw_j * q.rs[j];
+        wsg[L.Lx + (long)t * kNDX + j] = sc * g;
     }
     // Gauss-Newton L_xx = sc J^T W J (+ the state regularisation).  Only its q-block WITHOUT the momentum rows is formed here:
     //     L_qq' = J_c^T wc J_c + sum_f J_f^T w_f J_f + (state regularisation on q: Jlog6 block on the free-flyer, weights on the joints)
@@ -453,7 +496,7 @@ __device__ __forceinline__ void calc_assemble(const IkBatchArgs &a, long b, int 
                 av[6 * I + ks] = w * bv[6 * I + ks];
             }
         }
-        double *Lqq = ws + L.Lqq + (long)t * kLqqDoubles;
+        const gd_t Lqq = wsg + L.Lqq + (long)t * kLqqDoubles;
         mfma_acc_t a00 = mfma_acc_t{0.0, 0.0, 0.0, 0.0}, a01 = a00, a11 = a00;
         UNROLL_RBD for (int ks = 1; ks < 6; ++ks) {
             a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], a00, 0, 0, 0);
@@ -463,18 +506,20 @@ __device__ __forceinline__ void calc_assemble(const IkBatchArgs &a, long b, int 
         UNROLL_RBD for (int ks = 0; ks < 2; ++ks) {  // the Jlog6 block: rows / columns 0..5 of tile (0, 0)
             const int k = 4 * ks + lk;
             const bool ok = li < 6 && k < 6;
-            const double jl = q.JlT[ok ? li : 0][ok ? k : 0], swk = state_w[ok ? k : 0];
+            double swk = sw_k[0];       // state_w[k] of this lane's row (k = lk or 4 + lk), out of the six wave-uniform values
+            UNROLL_RBD for (int c = 1; c < 6; ++c) swk = (ok && k == c) ? sw_k[c] : swk;
+            const double jl = q.JlT[ok ? li : 0][ok ? k : 0];
             a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? wst * swk * jl : 0.0, ok ? jl : 0.0, a00, 0, 0, 0);
         }
-        const double sw0 = li >= 6 ? wst * state_w[li] : 0.0;            // the joints' part of the diagonal of tile (0, 0)
-        const double sw1 = wst * state_w[16 + (li < 2 ? li : 0)];        // ... of the 2 x 2 corner of tile (1, 1) (q 16, 17)
+        const double sw0 = li >= 6 ? wst * sw_li : 0.0;            // the joints' part of the diagonal of tile (0, 0)
+        const double sw1 = wst * sw_c;                              // ... of the 2 x 2 corner of tile (1, 1) (q 16, 17)
         UNROLL_RBD for (int v = 0; v < 4; ++v) Lqq[v * 64 + lane] = sc * (a00[v] + (lk + 4 * v == li ? sw0 : 0.0));
         if (li < 2) { UNROLL_RBD for (int v = 0; v < 4; ++v) Lqq[256 + (v * 4 + lk) * 2 + li] = sc * a01[v]; }
         if (li < 2 && lk < 2) Lqq[288 + lk * 2 + li] = sc * (a11[0] + (lk == li ? sw1 : 0.0));
         // the momentum weight and the velocity part of the state regularisation's diagonal, as the tiles (1,1) / (2,2) index it
-        double *Hn = ws + L.Hn + (long)t * kHnDoubles;
-        if (lane < 16) Hn[kHnD11 + lane] = lane >= 2 ? sc * wst * state_w[16 + lane] : 0.0;
-        else if (lane < 20) Hn[kHnD22 + lane - 16] = sc * wst * state_w[16 + lane];
+        const gd_t Hn = wsg + L.Hn + (long)t * kHnDoubles;
+        if (lane < 16) Hn[kHnD11 + lane] = lane >= 2 ? sc * wst * sw_t : 0.0;
+        else if (lane < 20) Hn[kHnD22 + lane - 16] = sc * wst * sw_t;
         else if (lane == 20) Hn[kHnW] = sc * wm;
     }
 }
@@ -505,11 +550,7 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a
     const double *state_w0 = batch_ptr(a.state_w, a.s_state_w, b), *ctrl_w0 = batch_ptr(a.ctrl_w, a.s_ctrl_w, b);
     {   // states and controls of both nodes: wave w stages node w
         const int t = t0 + wave;
-        if (t < nn) {
-            CalcNode &q = s.nd[wave];
-            if (lane < kNX) q.x[lane] = ws[L.xs + (long)t * kNX + lane];
-            if (lane < kNV) q.u[lane] = t == a.T ? 0.0 : ws[L.us + (long)t * kNV + lane];
-        }
+        if (t < nn) { const StagedNode v = calc_stage_load(a, b, t, ws, L, lane); calc_stage_store(a, t, s.nd[wave], lane, v); }
     }
     __syncthreads();
     PSTAMP(0)
@@ -517,7 +558,7 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a
     const int hs = lane >> 5, hl = lane & 31, tw = t0 + hs;
     const bool wvalid = tw < nn;
     CalcNode &qw = s.nd[hs];
-    NodeTasks tkw{a.tasks + (b * nn + (wvalid ? tw : t0)) * kNodeTaskDoubles};
+    NodeTasks tkw{qw.tk};
     PartWalk pw;
     double Rb[9], pb[3], Vb[6];
     if (wave == 0 && wvalid && hl < kNV) calc_walk(m, qw, tkw, hl, Rb, pb, Vb, pw);
@@ -576,23 +617,23 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff1_kernel(const IkBatchArgs 
     const int t0 = (int)(unit % groups) * kCalcNodes;
     const IkLayout L = IkLayout::make(a.T);
     double *ws = a.ws + b * L.total;
-    if (ws[L.scal + S_DONE] != 0.0 || ws[L.scal + S_RECALC] == 0.0) return;
     const RobotModelDev &m = s.m;
     CalcNode (&nd)[kCalcNodes] = s.nd[wave];
-    UNROLL_RBD for (int h = 0; h < kCalcNodes; ++h) {
-        const int t = t0 + h;
-        if (t < nn) {
-            CalcNode &q = nd[h];
-            if (lane < kNX) q.x[lane] = ws[L.xs + (long)t * kNX + lane];
-            if (lane < kNV) q.u[lane] = t == a.T ? 0.0 : ws[L.us + (long)t * kNV + lane];
-        }
+    {   // the problem's two flags and everything the pair needs from the workspace in ONE round trip (the flags first and the states
+        // behind their test were two)
+        const double f_done = ws[L.scal + S_DONE], f_recalc = ws[L.scal + S_RECALC];
+        const bool two = t0 + 1 < nn;
+        const StagedNode v0 = calc_stage_load(a, b, t0, ws, L, lane), v1 = calc_stage_load(a, b, two ? t0 + 1 : t0, ws, L, lane);
+        if (f_done != 0.0 || f_recalc == 0.0) return;
+        calc_stage_store(a, t0, nd[0], lane, v0);
+        if (two) calc_stage_store(a, t0 + 1, nd[1], lane, v1);
     }
     wave_sync();
     const int hs = lane >> 5, hl = lane & 31, tw = t0 + hs;
     const bool wvalid = tw < nn;
     CalcNode &qw = nd[hs];
     {
-        NodeTasks tkw{a.tasks + (b * nn + (wvalid ? tw : t0)) * kNodeTaskDoubles};
+        NodeTasks tkw{qw.tk};
         PartWalk pw;
         double Rb[9], pb[3], Vb[6];
         if (wvalid && hl < kNV) calc_walk(m, qw, tkw, hl, Rb, pb, Vb, pw);
@@ -1878,16 +1919,9 @@ __device__ __forceinline__ void producer_wave(const IkBatchArgs &a, long b, Fuse
         for (int pair = p; pair < npairs; pair += 2) {
             const int tA = T - 2 * pair, tB = tA - 1, tw = hs == 0 ? tA : tB;
             const bool wvalid = tw >= 0;
-            UNROLL_RBD for (int h = 0; h < kCalcNodes; ++h) {
-                const int t = h == 0 ? tA : tB;
-                if (t >= 0) {
-                    CalcNode &q = s.nd[p][h];
-                    if (lane < kNX) q.x[lane] = ws[L.xs + (long)t * kNX + lane];
-                    if (lane < kNV) q.u[lane] = t == T ? 0.0 : ws[L.us + (long)t * kNV + lane];
-                }
-            }
+            UNROLL_RBD for (int h = 0; h < kCalcNodes; ++h) { const int t = h == 0 ? tA : tB; if (t >= 0) calc_stage_simple(a, b, t, ws, L, s.nd[p][h], lane); }
             wave_sync();
-            NodeTasks tkw{a.tasks + (b * nn + (wvalid ? tw : tA)) * kNodeTaskDoubles};
+            NodeTasks tkw{qw.tk};
             PartWalk pw;
             double Rb[9], pb[3], Vb[6];
             if (wvalid && hl < kNV) calc_walk(m, qw, tkw, hl, Rb, pb, Vb, pw);

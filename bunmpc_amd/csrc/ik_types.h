@@ -11,7 +11,7 @@ namespace bunmpc {
 int set_error(int code, const std::string &msg);
 
 constexpr int kMaxJoints = 12;   // revolute joints after the free-flyer (serial chains off the base)
-constexpr int kMaxFrames = 64;
+constexpr int kMaxFrames = 40;   // (Solo12: 35 frames, Go2: 39; the table is part of the model copy every derivative workgroup keeps in LDS)
 constexpr int kNV = 18, kNQ = 19, kNX = 37, kNDX = 36;   // the kernels are built for 12 joints
 constexpr int kFrameSlots = 4;   // frame-translation tasks per node (the harness adds <= n_eff)
 

@@ -349,6 +349,22 @@ def test_work_stealing_does_not_change_results(hiplib):
     # (the violation is a segment sum: its order of additions depends on WHICH of the wave's three segments holds the problem)
     assert np.allclose(out[1]["dyn_viol"], out[0]["dyn_viol"], rtol=1e-12, atol=0)
     assert np.allclose(out[1]["hist"], out[0]["hist"], rtol=1e-12, atol=0, equal_nan=True)
+    # ... and from a WARM start with carried step constants (set_warm_start_vars; FISTA's L_ persists, fista.hpp:52): the segments
+    # then read a problem's iterates and L from the arrays when they take it, not only at the start of the launch
+    warm = {}
+    for on in (1, 0):
+        old = hiplib.bmpc_set_work_stealing(on)
+        try:
+            dev = bbm.DeviceBatch(b, num_iters=40)
+            dev.set_warm_start(out[0]["X"], out[0]["F"], out[0]["P"], L_x=out[0]["L_x"] * 1.5, L_f=out[0]["L_f"] * 0.5)
+            dev.solve()
+            warm[on] = dev.results()
+            assert hiplib.bmpc_biconvex_last_kernel_name().decode() == ("biconvex_admm_steal_kernel" if on else "biconvex_admm_kernel")
+        finally:
+            hiplib.bmpc_set_work_stealing(old)
+    for k in ("X", "F", "P", "L_x", "L_f", "stats"):
+        assert np.array_equal(warm[1][k], warm[0][k]), k
+    assert len(np.unique(warm[1]["stats"][:, 0])) > 3
 
 
 @pytest.mark.parametrize("which", ["batch", "wave"])
