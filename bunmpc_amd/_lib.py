@@ -87,6 +87,8 @@ _SIGS = {
     "bmpc_abi_version": (_I, []),
     "bmpc_set_three_per_wave": (_I, [_I]),
     "bmpc_set_work_stealing": (_I, [_I]),
+    "bmpc_set_two_waves_per_simd": (_I, [_I]),
+    "bmpc_biconvex_last_waves_per_simd": (_I, []),
     "bmpc_biconvex_last_lanes_per_problem": (_I, []),
     "bmpc_batch_struct_size": (_I, []),
     "bmpc_set_latency_mapping_max_batch": (_I, [_I]),

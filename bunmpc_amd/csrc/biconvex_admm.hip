@@ -45,12 +45,17 @@ namespace {
 
 #include "biconvex_admm_body.h"
 
-// fp64: ONE wave per SIMD.  The body holds 302-336 registers; capped at 256 (two waves per SIMD,
-// `__attribute__((amdgpu_waves_per_eu(2, 2)))`) the compiler parks 77-115 values in scratch memory.  Round 2 measured that build
-// 4 % faster at 14 x the HBM traffic (549 instead of 39.5 MB per launch: the scratch of 2048 waves does not stay in L2); against
-// this round's one-wave build it is level (4.11 vs 4.09 ms at B = 4096, 9.43 vs 9.30 ms on the Go2 shape).  Not taken.
-template <typename R, int LPP, int E, bool RAW, bool HASQF>
-__global__ __launch_bounds__(64) void biconvex_admm_kernel(const BatchArgs a) { admm_body<R, LPP, E, RAW, HASQF>(a); }
+// fp64, WPE = 1: ONE wave per SIMD.  The body holds 294 registers; capped at 256 with the FISTA iterates in registers the compiler parks
+// 63 of them in scratch memory, some inside the loops (round 2 measured that build 4 % faster at 14 x the HBM traffic, round 3 level).
+// WPE = 2 (round 4): two waves per SIMD with x_k and its image in LDS (biconvex_admm_body.h: XLDS) -- both FISTA loops free of
+// scratch accesses at 256 registers, the two waves of a SIMD covering each other's latencies.  A lone wave of this build is slower
+// than a lone wave of the other (2.30 against 1.94 ms: the LDS round trip sits on its chain), so it is taken where the batch
+// needs more waves than the chip has SIMDs and three problems per wave do not save a round (launch_biconvex_admm below):
+// B = 4096, H = 20: 3.74 against 4.02 ms.
+template <typename R, int LPP, int E, bool RAW, bool HASQF, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void biconvex_admm_kernel(const BatchArgs a) {
+    admm_body<R, LPP, E, RAW, HASQF, false, WPE == 2>(a);
+}
 // the work-stealing variant (biconvex_admm_body.h: STEAL): three problems per wave, harness form, fp64
 __global__ __launch_bounds__(64) void biconvex_admm_steal_kernel(const BatchArgs a) { admm_body<double, 21, 4, false, false, true>(a); }
 __global__ __launch_bounds__(64) void lane_selftest_kernel(const double *in, double *out) {
@@ -73,13 +78,14 @@ __global__ __launch_bounds__(64) void lane_selftest_kernel(const double *in, dou
 }
 
 template <typename R, int LPP, bool RAW, bool HASQF>
-hipError_t launch(const BatchArgs &a, hipStream_t stream) {
+hipError_t launch(const BatchArgs &a, bool two_per_simd, hipStream_t stream) {
     const int per_wave = 64 / LPP;
     const unsigned grid = (unsigned)((a.B + per_wave - 1) / per_wave);
-    const size_t nstate = 2 * 9 * (size_t)(a.H + 1) + 12 * (size_t)a.H;   // X, P, F of one problem
-    const size_t lds = sizeof(R) * ((((size_t)a.c.maxit + 1) & ~(size_t)1) + per_wave * nstate);
+    const size_t nstate = 3 * 9 * (size_t)(a.H + 1) + 13 * (size_t)a.H;   // X, P, F (at a stride of 13), R of one problem
+    const size_t lds = sizeof(R) * ((((size_t)a.c.maxit + 1) & ~(size_t)1) + kLdsZeros + per_wave * nstate);
     if (sizeof(R) == sizeof(float)) return launch_biconvex_admm_f32(a, LPP, grid, lds, stream);      // biconvex_admm_f32.hip
-    hipLaunchKernelGGL((biconvex_admm_kernel<double, LPP, 4, RAW, HASQF>), dim3(grid), dim3(64), lds, stream, a);
+    if (two_per_simd && LPP != 21) hipLaunchKernelGGL((biconvex_admm_kernel<double, LPP == 21 ? 32 : LPP, 4, RAW, HASQF, 2>), dim3(grid), dim3(64), lds, stream, a);
+    else hipLaunchKernelGGL((biconvex_admm_kernel<double, LPP, 4, RAW, HASQF, 1>), dim3(grid), dim3(64), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -102,20 +108,20 @@ hipError_t launch_steal(const BatchArgs &a, long simds, hipStream_t stream) {
     BatchArgs s = a;
     s.queue = steal_counter(stream);
     if (!s.queue) return hipErrorOutOfMemory;
-    const size_t nstate = 2 * 9 * (size_t)(a.H + 1) + 12 * (size_t)a.H;
-    const size_t lds = sizeof(double) * ((((size_t)a.c.maxit + 1) & ~(size_t)1) + 3 * nstate);
+    const size_t nstate = 3 * 9 * (size_t)(a.H + 1) + 13 * (size_t)a.H;
+    const size_t lds = sizeof(double) * ((((size_t)a.c.maxit + 1) & ~(size_t)1) + kLdsZeros + 3 * nstate);
     hipLaunchKernelGGL(biconvex_admm_steal_kernel, dim3((unsigned)simds), dim3(64), lds, stream, s);
     return hipGetLastError();
 }
 
 template <int LPP>
-hipError_t launch_lpp(const BatchArgs &a, hipStream_t stream) {
+hipError_t launch_lpp(const BatchArgs &a, bool two_per_simd, hipStream_t stream) {
     if (a.precision == 1) {   // fp32 arithmetic: harness form only
         if (a.raw || LPP == 21) return hipErrorInvalidValue;
-        return launch<float, LPP == 21 ? 32 : LPP, false, false>(a, stream);
+        return launch<float, LPP == 21 ? 32 : LPP, false, false>(a, false, stream);
     }
-    if (!a.raw) return launch<double, LPP, false, false>(a, stream);
-    return a.qf ? launch<double, LPP, true, true>(a, stream) : launch<double, LPP, true, false>(a, stream);
+    if (!a.raw) return launch<double, LPP, false, false>(a, two_per_simd, stream);
+    return a.qf ? launch<double, LPP, true, true>(a, two_per_simd, stream) : launch<double, LPP, true, false>(a, two_per_simd, stream);
 }
 
 }  // namespace
@@ -144,6 +150,17 @@ static bool three_per_wave_pays(const BatchArgs &a) {
     const long simds = chip_simds(), w3 = (a.B + 2) / 3, w2 = (a.B + 1) / 2;
     return (w3 + simds - 1) / simds < (w2 + simds - 1) / simds || a.c.num_iters >= 25;
 }
+// Two waves per SIMD (the XLDS build): 0 never, 1 whenever the kernel exists for the shape (16 / 32 / 64 lanes per problem, fp64),
+// 2 (default) where it is the faster one: the batch needs more waves than the chip has SIMDs.  Results do not depend on it.
+static int g_two_per_simd = 2;
+int set_two_waves_per_simd(int mode) { const int old = g_two_per_simd; g_two_per_simd = mode; return old; }
+static bool two_per_simd_pays(const BatchArgs &a, int per_wave) {
+    if (a.precision != 0 || g_two_per_simd == 0) return false;
+    if (g_two_per_simd == 1) return true;
+    return (a.B + per_wave - 1) / per_wave > chip_simds();
+}
+static thread_local int t_last_wpe = 1;
+int biconvex_last_waves_per_simd() { return t_last_wpe; }
 static int g_work_stealing = 1;       // 0: never the work-stealing kernel (tests: results must not depend on it)
 int set_work_stealing(int on) { const int old = g_work_stealing; g_work_stealing = on; return old; }
 static int g_latency_max_batch = 1024;
@@ -174,7 +191,8 @@ hipError_t launch_biconvex_admm(const BatchArgs &a, int n_eff, hipStream_t strea
     }
     const int k = a.H + 1;
     t_last_kernel = a.precision == 1 ? "biconvex_admm_kernel_f32" : "biconvex_admm_kernel";
-    if (k <= 16) { t_last_lpp = 16; return launch_lpp<16>(a, stream); }
+    t_last_wpe = 1;
+    if (k <= 16) { t_last_lpp = 16; const bool w2 = two_per_simd_pays(a, 4); t_last_wpe = w2 ? 2 : 1; return launch_lpp<16>(a, w2, stream); }
     // 17..21 knots (the headline shape): three problems per wave in 21-lane segments (fp64; the fp32 kernels keep 32-lane segments)
     if (k <= 21 && k > 16 && a.precision == 0 && three_per_wave_pays(a)) {
         t_last_lpp = 21;
@@ -185,11 +203,13 @@ hipError_t launch_biconvex_admm(const BatchArgs &a, int n_eff, hipStream_t strea
             t_last_kernel = "biconvex_admm_steal_kernel";
             return launch_steal(a, S, stream);
         }
-        return launch_lpp<21>(a, stream);
+        return launch_lpp<21>(a, false, stream);
     }
     t_last_lpp = k <= 32 ? 32 : 64;
-    if (k <= 32) return launch_lpp<32>(a, stream);
-    return launch_lpp<64>(a, stream);
+    const bool w2 = two_per_simd_pays(a, 64 / t_last_lpp);
+    t_last_wpe = w2 ? 2 : 1;
+    if (k <= 32) return launch_lpp<32>(a, w2, stream);
+    return launch_lpp<64>(a, w2, stream);
 }
 
 hipError_t launch_lane_selftest(const double *in, double *out, hipStream_t stream) {

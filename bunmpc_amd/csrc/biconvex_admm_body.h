@@ -25,7 +25,13 @@
 // wave is done (a wave's time was the MAXIMUM over its three problems; the batch's now approaches the SUM over all problems / the
 // number of segments).  The arithmetic of a problem does not depend on which segment runs it, or when.  Addresses in this mode are
 // the arrays' own bases + 32-bit byte offsets from the problem index (the host checks that they fit).
-template <typename R, int LPP, int E, bool RAW, bool HASQF, bool STEAL = false>
+//
+// XLDS (round 4; the build for TWO waves per SIMD, 256 registers): the FISTA loops keep y and its image in registers only; x_k and
+// ITS image rest in LDS (the problem's X / F block and an R block beside them).  An iteration reads them once -- while the segment
+// sums of its step are being reduced -- for the momentum step, and leaves x_{k+1} there under the mask of the problems still
+// iterating, which is also the latch of a finishing problem.  36 registers less across the loops than two register copies whose
+// roles swap: both loops are free of scratch accesses at 256 registers.  Same operations in the same order: same bits.
+template <typename R, int LPP, int E, bool RAW, bool HASQF, bool STEAL = false, bool XLDS = false>
 __device__ __forceinline__ void admm_body(const BatchArgs &a) {
     extern __shared__ double lds_raw[];
     R *cmtab = reinterpret_cast<R *>(lds_raw);   // [maxit]
@@ -51,12 +57,17 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
 
     // Iterates at phase boundaries (X, F, P of this segment's problem) live in LDS, each lane touching
     // only its own knot's blocks (lane 0 also the x_init rows of P): HBM sees the inputs once and the
-    // results once.  Layout after the momentum table: per segment [X nx | P nx | F nf].
-    R *seg_lds = cmtab + ((maxit + 1) & ~1) + (long)seg * (2 * nx + nf);
+    // results once.  Layout after the momentum table: some zeros, then per segment [X nx | P nx | F 13 H | R nx].
+    // (F blocks at a stride of NF + 1: at 12 doubles lanes t, t + 8, t + 16 would share their LDS banks)
+    constexpr int FS = NF + 1;
+    R *zeros = cmtab + ((maxit + 1) & ~1);        // kLdsZeros zeros: what a lane without a knot reads for x_k (XLDS)
+    R *seg_lds = zeros + kLdsZeros + (long)seg * (3 * nx + (long)FS * H);
     R *Xg = seg_lds + 9L * t;
     R *Pg = seg_lds + nx + 9L * t;
     R *PIg = seg_lds + nx + 9L * H;
-    R *Fg = seg_lds + 2 * nx + (long)NF * t;
+    R *Fg = seg_lds + 2 * nx + (long)FS * t;
+    R *Rg = seg_lds + 2 * nx + (long)FS * H + 9L * t;      // XLDS: the affine image of the FISTA loops' x_k
+    const R *Fz = rvalid ? Fg : zeros, *RFz = rvalid ? Rg : zeros, *Xz = kvalid ? Xg : zeros, *RXz = kvalid ? Rg : zeros;
     // Global arrays are addressed as a WAVE-UNIFORM base (the block of the wave's first problem: scalar registers) plus a 32-bit
     // per-lane byte offset (problem within the wave, knot): `global_load v, v_off, s[base]`.  A 64-bit pointer per lane and array
     // -- what `a.X + pb * nx + 9 * t` makes -- held some thirty vector registers over both FISTA loops, and they were what the
@@ -87,6 +98,7 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
             if (lane == 0) cmtab[i] = (R)((tk - 1.0) / tk1);
             tk = tk1;
         }
+        if (lane < kLdsZeros) zeros[lane] = R(0);
         __syncthreads();
     }
 
@@ -224,13 +236,20 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
             UNROLL for (int j = 0; j < NF; ++j) { xa[j] = rvalid ? Fg[j] : R(0); y[j] = xa[j]; }
             applyA(y, ry);
             UNROLL for (int k = 0; k < 6; ++k) ra[k] = ry[k];
+            if (XLDS && rvalid) { UNROLL for (int k = 0; k < 6; ++k) Rg[k] = ry[k]; }      // (x_0 itself is in the F block already)
             const R mu2 = mu * mu, imu = R(1) / (mu * mu + R(1));
             const double tol2 = tol * tol;
             R invL = R(2) * (R(1) / L_f);      // 2 / L, see above
             mask_t act = alive;
-            // one FISTA iteration: reads x from xo/ro, leaves x_{k+1} in xn/rn, advances y/ry
-            auto iterate = [&](const R (&xo)[NF], const R (&ro)[6], R (&xn)[NF], R (&rn)[6], int i) {
+            // one FISTA iteration: reads x from xo/ro, leaves x_{k+1} in xn/rn, advances y/ry (XLDS: x_k from LDS, x_{k+1} to LDS;
+            // the four arrays are then no more than the iteration's temporaries)
+            auto iterate = [&](const R (&xo_reg)[NF], const R (&ro_reg)[6], R (&xn)[NF], R (&rn)[6], int i) {
                 const R cm = cmtab[i];
+                R xo[NF], ro[6];
+                if (!XLDS) {
+                    UNROLL for (int j = 0; j < NF; ++j) xo[j] = xo_reg[j];
+                    UNROLL for (int k = 0; k < 6; ++k) ro[k] = ro_reg[k];
+                }
                 mask_t done;
                 mask_t pend = act;
                 for (;;) {  // backtracking (fista.cpp:8-26); segments that accepted recompute the same values
@@ -295,6 +314,10 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
                         e2 = s0 * s0 + s1 * s1 + s2 * s2 + s3 * s3 + s4 * s4 + s5 * s5;
                     }
                     cv = fmaR(rho, e2, cv);
+                    if (XLDS) {     // x_k and its image come in while the sums are reduced (unconditional: lanes without a knot read zeros)
+                        UNROLL for (int j = 0; j < NF; ++j) xo[j] = Fz[j];
+                        UNROLL for (int k = 0; k < 6; ++k) ro[k] = RFz[k];
+                    }
                     double g2s = (double)g2, cvs = (double)cv;
                     seg_sum2<LPP>(g2s, cvs);
                     // fista.cpp:14-17: G = sqrt(g2); retry if cv > (L/2) G*G; done if G < tol.  G*G and g2
@@ -311,17 +334,27 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
                     }
                     bt = seg_uniform<LPP>(bt);      // (LPP = 21: the sums live at three lanes; their decisions go to their segments)
                     done = seg_uniform<LPP>(done);
+                    if (XLDS) {     // a use that stays in this loop: without it hipcc sinks the reads to the momentum step, where their latency shows
+                        UNROLL for (int j = 0; j < NF; ++j) keep_here(xo[j]);
+                        UNROLL for (int k = 0; k < 6; ++k) keep_here(ro[k]);
+                    }
                     bt &= pend;
                     pend = bt;
                     if (bt == 0) break;
                     if (lanes(bt)) { L_f *= beta; ++bt_f; }
                     invL = R(2) * (R(1) / L_f);
                 }
-                const mask_t last = act & (i == maxit - 1 ? ~mask_t(0) : done) & rvalid_m;
-                if (lanes(last)) { UNROLL for (int j = 0; j < NF; ++j) Fg[j] = xn[j]; }   // x_k of a finishing problem is latched
+                if (!XLDS) {
+                    const mask_t last = act & (i == maxit - 1 ? ~mask_t(0) : done) & rvalid_m;
+                    if (lanes(last)) { UNROLL for (int j = 0; j < NF; ++j) Fg[j] = xn[j]; }   // x_k of a finishing problem is latched
+                }
                 // momentum (fista.cpp:33-47); A-images follow by linearity
                 UNROLL for (int j = 0; j < NF; ++j) y[j] = fmaR(cm, xn[j] - xo[j], xn[j]);
                 UNROLL for (int k = 0; k < 6; ++k) ry[k] = fmaR(cm, rn[k] - ro[k], rn[k]);
+                if (XLDS && lanes(act & rvalid_m)) {      // problems still iterating (a finished one keeps the x_k it finished with)
+                    UNROLL for (int j = 0; j < NF; ++j) Fg[j] = xn[j];
+                    UNROLL for (int k = 0; k < 6; ++k) Rg[k] = rn[k];
+                }
                 it_f += lanes(act) ? 1 : 0;
                 act &= ~done;
             };
@@ -429,11 +462,14 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
             UNROLL for (int l = 0; l < 9; ++l) { xa[l] = kvalid ? Xg[l] : R(0); y[l] = xa[l]; }
             applyA(y, ry);
             UNROLL for (int l = 0; l < 9; ++l) ra[l] = ry[l];
+            if (XLDS && kvalid) { UNROLL for (int l = 0; l < 9; ++l) Rg[l] = ry[l]; }
             const double tol2 = tol * tol;
             R invL = R(2) * (R(1) / L_x);
             mask_t act = alive;
-            auto iterate = [&](const R (&xo)[9], const R (&ro)[9], R (&xn)[9], R (&rn)[9], int i) {
+            auto iterate = [&](const R (&xo_reg)[9], const R (&ro_reg)[9], R (&xn)[9], R (&rn)[9], int i) {
                 const R cm = cmtab[i];
+                R xo[9], ro[9];
+                if (!XLDS) { UNROLL for (int l = 0; l < 9; ++l) { xo[l] = xo_reg[l]; ro[l] = ro_reg[l]; } }
                 mask_t done;
                 mask_t pend = act;
                 for (;;) {
@@ -463,6 +499,7 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
                         e2 = fmaR(e, e, e2);
                     }
                     cv = fmaR(rho, e2, cv);
+                    if (XLDS) { UNROLL for (int l = 0; l < 9; ++l) { xo[l] = Xz[l]; ro[l] = RXz[l]; } }      // (see the force step)
                     double g2s = (double)g2, cvs = (double)cv;
                     seg_sum2<LPP>(g2s, cvs);
                     const double Lh = (double)L_x * 0.5, rhs = Lh * g2s;   // see the force loop for the sqrt-free form
@@ -476,18 +513,22 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
                     }
                     bt = seg_uniform<LPP>(bt);      // (LPP = 21: the sums live at three lanes; their decisions go to their segments)
                     done = seg_uniform<LPP>(done);
+                    if (XLDS) { UNROLL for (int l = 0; l < 9; ++l) { keep_here(xo[l]); keep_here(ro[l]); } }
                     bt &= pend;
                     pend = bt;
                     if (bt == 0) break;
                     if (lanes(bt)) { L_x *= beta; ++bt_x; }
                     invL = R(2) * (R(1) / L_x);
                 }
-                const mask_t last = act & (i == maxit - 1 ? ~mask_t(0) : done) & kvalid_m;
-                if (lanes(last)) { UNROLL for (int l = 0; l < 9; ++l) Xg[l] = xn[l]; }
+                if (!XLDS) {
+                    const mask_t last = act & (i == maxit - 1 ? ~mask_t(0) : done) & kvalid_m;
+                    if (lanes(last)) { UNROLL for (int l = 0; l < 9; ++l) Xg[l] = xn[l]; }
+                }
                 UNROLL for (int l = 0; l < 9; ++l) {
                     y[l] = fmaR(cm, xn[l] - xo[l], xn[l]);
                     ry[l] = fmaR(cm, rn[l] - ro[l], rn[l]);
                 }
+                if (XLDS && lanes(act & kvalid_m)) { UNROLL for (int l = 0; l < 9; ++l) { Xg[l] = xn[l]; Rg[l] = rn[l]; } }
                 it_x += lanes(act) ? 1 : 0;
                 act &= ~done;
             };

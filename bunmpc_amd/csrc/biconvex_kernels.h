@@ -52,6 +52,7 @@ struct BatchArgs {
 };
 
 constexpr int kStats = 6;
+constexpr int kLdsZeros = 12;          // zeros in LDS behind the momentum table (biconvex_admm_body.h: lanes without a knot read them)
 constexpr int kMaxFistaIters = 4096;  // momentum table lives in LDS (8 B per iteration): 32 KB + <= 30 KB of iterates < 64 KB
 constexpr int kMaxKnots = 64;  // H + 1 <= 64: one knot per lane, one problem per <=64 lanes
 
@@ -65,6 +66,8 @@ bool latency_mapping_fits(const BatchArgs &a, int n_eff);
 hipError_t launch_biconvex_latency(const BatchArgs &a, hipStream_t stream);
 int set_latency_mapping_max_batch(int max_batch);   // returns the old value
 int set_three_per_wave(int mode);                    // 21-lane segments for 17..21 knots: 0 never, 1 always, 2 when it pays (default); returns the old value
+int set_two_waves_per_simd(int mode);               // the two-waves-per-SIMD build of the fp64 batch kernel: 0 never, 1 always, 2 when it pays (default); returns the old value
+int biconvex_last_waves_per_simd();                  // of the calling host thread's latest launch (1 or 2)
 int set_work_stealing(int on);                       // the segment-level work-stealing kernel for num_iters >= 25 (default on); returns the old value
 int biconvex_last_lanes_per_problem();               // of the calling host thread's latest launch: 16 / 21 / 32 / 64, 0 = one problem per wave
 int set_exact_step_decisions(int on);                // ... takes every step decision from the fp64 sums; returns the old value

@@ -179,6 +179,9 @@ __device__ __forceinline__ double *at(double *ubase, unsigned byte_off) {
 // during a solve, so with plain offsets hipcc hoists the LOADED VALUES (weights, contact plan, bounds: ~60 registers) out of the
 // ADMM loop and carries them across both FISTA loops; re-reading them in each of the ten ADMM iterations (L2-resident) is free.
 __device__ __forceinline__ unsigned opaque_zero() { unsigned z = 0; asm volatile("" : "+v"(z)); return z; }
+// a use of v the optimiser cannot move or remove (no instruction)
+__device__ __forceinline__ void keep_here(double &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void keep_here(float &v) { asm volatile("" : "+v"(v)); }
 // HBM holds fp64 whatever the arithmetic type R of the kernel; conversion happens at the load / store
 // (the constant element index stays outside the 32-bit offset: it folds into the instruction's immediate)
 // The load is UNCONDITIONAL (the caller's offset names an existing element in every lane); `ok` only decides what is kept.

@@ -167,8 +167,16 @@ int bmpc_set_three_per_wave(int mode);
  * ("biconvex_admm_steal_kernel"): the batch takes the sum of the problems' iterations over the segments, not the per-wave maxima.
  * A problem's result does not depend on it.  on = 0: never (a test switch).  Default 1.  Returns the old value. */
 int bmpc_set_work_stealing(int on);
+/* The fp64 batch kernel (16 / 32 / 64 lanes per problem) exists in two builds: for ONE wave per SIMD (FISTA iterates in registers,
+ * ~290 of them) and for TWO (256 registers: x_k and its affine image rest in LDS between the iterations; same operations in the
+ * same order, bit-identical results).  A lone wave of the second build is the slower one, two of them on a SIMD cover each
+ * other's latencies.  mode 0: never the second, 1: always, 2 (default): when the batch needs more waves than the chip has SIMDs
+ * (B = 4096 at n_col = 20 on an MI355X: 2048 waves over 1024 SIMDs).  Returns the old value. */
+int bmpc_set_two_waves_per_simd(int mode);
 /* lanes per problem of the calling host thread's latest batch solve: 16 / 21 / 32 / 64, 0 = the one-problem-per-wave kernel */
 int bmpc_biconvex_last_lanes_per_problem(void);
+/* ... and the waves per SIMD its kernel was built for (1 or 2) */
+int bmpc_biconvex_last_waves_per_simd(void);
 /* The one-problem-per-wave kernel takes the two decisions of a FISTA step (retry, fista.cpp:16; exit, fista.cpp:29) from fp32
  * wave sums whenever both comparisons are clear of their thresholds by 1e-5 relative, from the fp64 sums and the reference
  * expression otherwise.  on = 1: always from the fp64 sums (a test switch: results must be bit-identical either way).

@@ -318,6 +318,60 @@ def test_three_problems_per_wave_equal_two_per_wave(oracle, hiplib, mapping, con
     assert np.array_equal(out[1]["stats"][calm], ref["stats"][calm])
 
 
+@pytest.mark.parametrize("config,B,H,iters,warm", [("solo12_trot", 100, None, 10, False), ("solo12_mixed", 31, None, 10, False), ("solo12_trot", 9, 12, 4, False),
+                                                   ("solo12_trot", 5, 28, 3, False), ("go2_bound", 6, 40, 3, False), ("solo12_trot", 33, None, 3, True)])
+def test_two_waves_per_simd_build_is_bit_identical(hiplib, mapping, config, B, H, iters, warm):
+    """The fp64 batch kernel has a second build for two waves per SIMD (256 registers: x_k of the FISTA loops and its affine image
+    rest in LDS between the iterations, bmpc_set_two_waves_per_simd).  Same operations in the same order: EVERY output bit for bit
+    as from the one-wave build -- iterates, step constants, violation history, every per-iteration count -- with 16 / 32 / 64
+    lanes per problem, partly filled waves, the chaotic mixed-gait batch, warm starts with carried step constants."""
+    mapping("batch")
+    b = problems.make_batch(config, B, H=H) if H else problems.make_batch(config, B)
+    old3 = hiplib.bmpc_set_three_per_wave(0)
+    out = {}
+    try:
+        for mode in (1, 0):
+            old = hiplib.bmpc_set_two_waves_per_simd(mode)
+            try:
+                r = bb.solve_host(b, num_iters=iters, keep_hist=True)
+                assert hiplib.bmpc_biconvex_last_waves_per_simd() == (2 if mode else 1)
+                if warm:      # a second call of the same solver objects: iterates and step constants carried over
+                    r = bb.solve_host(b, num_iters=iters, keep_hist=True, warm=(r["X"], r["F"], r["P"]), L_x=r["L_x"], L_f=r["L_f"])
+                out[mode] = r
+            finally:
+                hiplib.bmpc_set_two_waves_per_simd(old)
+    finally:
+        hiplib.bmpc_set_three_per_wave(old3)
+    for k in ("X", "F", "P", "L_x", "L_f", "stats", "trace"):
+        assert np.array_equal(out[1][k], out[0][k]), k
+    for k in ("hist", "dyn_viol"):
+        assert np.array_equal(out[1][k], out[0][k], equal_nan=True), k
+
+
+def test_two_waves_per_simd_raw_form_is_bit_identical(hiplib, mapping):
+    """... and the raw cost / bound form (set_cost_x / set_bounds_x / set_cost_f given explicitly, with and without a linear force
+    cost), whose instantiations are separate kernels."""
+    mapping("batch")
+    b = problems.make_batch("solo12_trot", 11)
+    rng = np.random.default_rng(5)
+    nx, nf = 9 * (b.H + 1), 12 * b.H
+    for with_qf in (False, True):
+        raw = dict(Qx=rng.uniform(0.5, 50.0, (b.B, nx)), qx=rng.normal(0.0, 1.0, (b.B, nx)), lbx=np.full((b.B, nx), -2.0), ubx=np.full((b.B, nx), 2.0),
+                   Qf=rng.uniform(1e-4, 1e-2, (b.B, nf)))
+        if with_qf:
+            raw["qf"] = rng.normal(0.0, 1e-3, (b.B, nf))
+        out = {}
+        for mode in (1, 0):
+            old = hiplib.bmpc_set_two_waves_per_simd(mode)
+            try:
+                out[mode] = bb.solve_host(b, num_iters=4, keep_hist=True, raw=raw)
+                assert hiplib.bmpc_biconvex_last_waves_per_simd() == (2 if mode else 1)
+            finally:
+                hiplib.bmpc_set_two_waves_per_simd(old)
+        for k in ("X", "F", "P", "L_x", "L_f", "stats", "trace", "hist"):
+            assert np.array_equal(out[1][k], out[0][k], equal_nan=True), (with_qf, k)
+
+
 def test_work_stealing_does_not_change_results(hiplib):
     """num_iters = 100 (the reference's own call): the ADMM's early exit makes the iteration counts differ per problem, and the
     three-per-wave kernel runs as a persistent grid whose segments take the next unsolved problem when theirs has finished
