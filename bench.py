@@ -474,6 +474,7 @@ def biconvex_leg(D, args):
     last_kernel = {"biconvex_admm_kernel": "biconvex_admm_kernel<double>"}.get(last_kernel, last_kernel)
     prec = {"f64": "fp64", "f32": "fp32 iterates, fp64 decisions"}[args.precision]
     lpp = int(bb._lib.lib().bmpc_biconvex_last_lanes_per_problem())
+    wpe = int(bb._lib.lib().bmpc_biconvex_last_waves_per_simd())
     out = {
         "metric": "MPC solves/sec (batch, whole node), %s, %d ADMM iters, %s" % (METRIC_SHAPE.get(args.config, args.config), args.admm_iters, prec),
         "value": total / elapsed, "unit": "solves/s", "n_gpus": W, "steps": args.steps,
@@ -485,7 +486,7 @@ def biconvex_leg(D, args):
                    "global_batch": B * W, "parallelism": "batch-shard x%d" % W},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": last_kernel, "lanes_per_problem": lpp, "kernel_ms": kern_ms,
+                     "kernel": last_kernel, "lanes_per_problem": lpp, "waves_per_simd": wpe, "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_launch": abytes,
                      "valu": {"model_flops_per_launch": flops,
                               "achieved_tflops": flops / (kern_ms * 1e-3) / 1e12,
@@ -497,8 +498,8 @@ def biconvex_leg(D, args):
 
 
 def other_batch_size_leg(D, args, B):
-    """Informational: the same kernel at a batch size where three problems per wave save a round of waves (bmpc_set_three_per_wave:
-    B = 6144 is 2048 waves of three = two rounds over the 1024 SIMDs, 3072 waves of two would be three)"""
+    """Informational: the same kernel at a batch size where three problems per wave fill the chip exactly (bmpc_set_three_per_wave,
+    bmpc_set_two_waves_per_simd: B = 6144 is 2048 waves of three, two per SIMD)"""
     import torch
     from bunmpc_amd import batch as bb
     from bunmpc_amd import problems
@@ -507,7 +508,8 @@ def other_batch_size_leg(D, args, B):
     dt = D.timed(db.solve, 10, 2) / 10
     r = db.results()
     return {"batch": B, "value": D.world * B / dt, "unit": "solves/s", "ms_per_step": dt * 1e3, "diverged": int((r["stats"][:, 5] != 0).sum()),
-            "lanes_per_problem": int(bb._lib.lib().bmpc_biconvex_last_lanes_per_problem())}
+            "lanes_per_problem": int(bb._lib.lib().bmpc_biconvex_last_lanes_per_problem()),
+            "waves_per_simd": int(bb._lib.lib().bmpc_biconvex_last_waves_per_simd())}
 
 
 def fp32_parity_note(pb, args):

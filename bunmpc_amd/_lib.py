@@ -88,6 +88,7 @@ _SIGS = {
     "bmpc_set_three_per_wave": (_I, [_I]),
     "bmpc_set_work_stealing": (_I, [_I]),
     "bmpc_set_two_waves_per_simd": (_I, [_I]),
+    "bmpc_set_steal_grid": (_I, [_I]),
     "bmpc_biconvex_last_waves_per_simd": (_I, []),
     "bmpc_biconvex_last_lanes_per_problem": (_I, []),
     "bmpc_batch_struct_size": (_I, []),

@@ -57,7 +57,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     admm_body<R, LPP, E, RAW, HASQF, false, WPE == 2>(a);
 }
 // the work-stealing variant (biconvex_admm_body.h: STEAL): three problems per wave, harness form, fp64
-__global__ __launch_bounds__(64) void biconvex_admm_steal_kernel(const BatchArgs a) { admm_body<double, 21, 4, false, false, true>(a); }
+template <int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void biconvex_admm_steal_kernel(const BatchArgs a) {
+    admm_body<double, 21, 4, false, false, true, WPE == 2>(a);
+}
 __global__ __launch_bounds__(64) void lane_selftest_kernel(const double *in, double *out) {
     const int i = threadIdx.x;
     const double v = in[i];
@@ -82,11 +85,38 @@ hipError_t launch(const BatchArgs &a, bool two_per_simd, hipStream_t stream) {
     const int per_wave = 64 / LPP;
     const unsigned grid = (unsigned)((a.B + per_wave - 1) / per_wave);
     const size_t nstate = 3 * 9 * (size_t)(a.H + 1) + 13 * (size_t)a.H;   // X, P, F (at a stride of 13), R of one problem
-    const size_t lds = sizeof(R) * ((((size_t)a.c.maxit + 1) & ~(size_t)1) + kLdsZeros + per_wave * nstate);
+    const size_t lds = sizeof(R) * (kLdsZeros + per_wave * nstate);
     if (sizeof(R) == sizeof(float)) return launch_biconvex_admm_f32(a, LPP, grid, lds, stream);      // biconvex_admm_f32.hip
-    if (two_per_simd && LPP != 21) hipLaunchKernelGGL((biconvex_admm_kernel<double, LPP == 21 ? 32 : LPP, 4, RAW, HASQF, 2>), dim3(grid), dim3(64), lds, stream, a);
+    if (two_per_simd) hipLaunchKernelGGL((biconvex_admm_kernel<double, LPP, 4, RAW, HASQF, 2>), dim3(grid), dim3(64), lds, stream, a);
     else hipLaunchKernelGGL((biconvex_admm_kernel<double, LPP, 4, RAW, HASQF, 1>), dim3(grid), dim3(64), lds, stream, a);
     return hipGetLastError();
+}
+
+// FISTA's momentum coefficients: t+ = 1 + sqrt(1 + 4 t^2)/2 (sic, fista.cpp:34), c_k = (t_k - 1)/t_{k+1} -- a function of k alone, so
+// one table per device, filled once by this kernel (until round 4 every wave tabulated them in its LDS: 1.2 KB of the 20 KB a wave
+// may hold when eight of them share a CU)
+__global__ void momentum_table_kernel(double *tab, int n) {
+    double tk = 1.0;
+    for (int i = 0; i < n; ++i) {
+        const double tk1 = 1.0 + sqrt(1.0 + 4.0 * tk * tk) * 0.5;
+        tab[i] = (tk - 1.0) / tk1;
+        tk = tk1;
+    }
+}
+const double *momentum_table(hipStream_t stream) {
+    static std::mutex lock;
+    static double *tab[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> hold(lock);
+    if (!tab[dev]) {
+        double *t = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&t), kMaxFistaIters * sizeof(double)) != hipSuccess) return nullptr;
+        hipLaunchKernelGGL(momentum_table_kernel, dim3(1), dim3(1), 0, stream, t, kMaxFistaIters);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { (void)hipFree(t); return nullptr; }      // (once per device: later launches on any stream find it filled)
+        tab[dev] = t;
+    }
+    return tab[dev];
 }
 
 // Device counters of the work-stealing launches: a ring of 64 per device, one per launch in flight (a launch zeroes its own on its
@@ -103,14 +133,17 @@ int *steal_counter(hipStream_t stream) {
     if (hipMemsetAsync(c, 0, sizeof(int), stream) != hipSuccess) return nullptr;
     return c;
 }
-// the persistent grid of the work-stealing kernel: one wave per SIMD is what its registers allow
-hipError_t launch_steal(const BatchArgs &a, long simds, hipStream_t stream) {
+// the persistent grid of the work-stealing kernel: as many waves as the chip holds at once (one or two per SIMD)
+int g_steal_grid = 0;      // waves of the persistent grid (experiments, set_steal_grid below): 0 = one or two per SIMD
+hipError_t launch_steal(const BatchArgs &a, long simds, bool two_per_simd, hipStream_t stream) {
     BatchArgs s = a;
     s.queue = steal_counter(stream);
     if (!s.queue) return hipErrorOutOfMemory;
     const size_t nstate = 3 * 9 * (size_t)(a.H + 1) + 13 * (size_t)a.H;
-    const size_t lds = sizeof(double) * ((((size_t)a.c.maxit + 1) & ~(size_t)1) + kLdsZeros + 3 * nstate);
-    hipLaunchKernelGGL(biconvex_admm_steal_kernel, dim3((unsigned)simds), dim3(64), lds, stream, s);
+    const size_t lds = sizeof(double) * (kLdsZeros + 3 * nstate);
+    const long waves = g_steal_grid > 0 ? std::min<long>(g_steal_grid, (a.B + 2) / 3) : (two_per_simd ? 2 * simds : simds);
+    if (two_per_simd) hipLaunchKernelGGL(biconvex_admm_steal_kernel<2>, dim3((unsigned)waves), dim3(64), lds, stream, s);
+    else hipLaunchKernelGGL(biconvex_admm_steal_kernel<1>, dim3((unsigned)waves), dim3(64), lds, stream, s);
     return hipGetLastError();
 }
 
@@ -134,6 +167,7 @@ hipError_t launch_lpp(const BatchArgs &a, bool two_per_simd, hipStream_t stream)
 // (num_iters well above ten: the ADMM's early exit, biconvex.cpp:111-114, makes the iteration counts differ per problem and the
 // scheduler backfills; measured at num_iters = 100, B = 4096: 31 -> 28 ms).  (Tried and dropped: B = 4096 as one round of three per
 // wave for 3072 problems + the one-problem-per-wave kernel for the other 1024 -- 2.29 + 1.7 ms, level with 2 x 2.02 ms.)
+int set_steal_grid(int waves) { const int old = g_steal_grid; g_steal_grid = waves; return old; }
 static int g_three_per_wave = 2;
 int set_three_per_wave(int on) { const int old = g_three_per_wave; g_three_per_wave = on; return old; }
 static long chip_simds() {
@@ -173,7 +207,8 @@ static thread_local int t_last_lpp = 0;       // lanes per problem of that launc
 int biconvex_last_lanes_per_problem() { return t_last_lpp; }
 const char *biconvex_last_kernel_name() { return t_last_kernel; }
 
-hipError_t launch_biconvex_admm(const BatchArgs &a, int n_eff, hipStream_t stream) {
+hipError_t launch_biconvex_admm(const BatchArgs &args, int n_eff, hipStream_t stream) {
+    BatchArgs a = args;
     if (n_eff != 4 || a.H < 1 || a.H + 1 > kMaxKnots || a.B < 0 || (a.precision != 0 && a.precision != 1))
         return hipErrorInvalidValue;
     if (a.B == 0) return hipSuccess;
@@ -189,6 +224,8 @@ hipError_t launch_biconvex_admm(const BatchArgs &a, int n_eff, hipStream_t strea
         al.exact_step_decisions = g_exact_step_decisions;
         return launch_biconvex_latency(al, stream);
     }
+    a.cmtab = momentum_table(stream);
+    if (!a.cmtab) return hipErrorOutOfMemory;
     const int k = a.H + 1;
     t_last_kernel = a.precision == 1 ? "biconvex_admm_kernel_f32" : "biconvex_admm_kernel";
     t_last_wpe = 1;
@@ -201,9 +238,15 @@ hipError_t launch_biconvex_admm(const BatchArgs &a, int n_eff, hipStream_t strea
         const long S = chip_simds(), per = std::max<long>({(long)a.H * 128, 9L * (a.H + 1) * 8, a.sW_X * 8, a.sW_F * 8, a.sbounds * 8, (long)a.c.num_iters * 16});
         if (g_work_stealing && !a.raw && a.c.num_iters >= 25 && (a.B + 2) / 3 > S && (double)a.B * (double)per < 2.0e9) {
             t_last_kernel = "biconvex_admm_steal_kernel";
-            return launch_steal(a, S, stream);
+            // (one wave per SIMD unless forced: measured at B = 4096, num_iters = 100: 30.7 ms; the two-waves build with grids of
+            // 1024 .. 2048 waves 34.2 .. 37.3 ms -- the stealing itself already fills the gaps the second wave would)
+            const bool w2 = g_two_per_simd == 1;
+            t_last_wpe = w2 ? 2 : 1;
+            return launch_steal(a, S, w2, stream);
         }
-        return launch_lpp<21>(a, false, stream);
+        const bool w2 = two_per_simd_pays(a, 3);
+        t_last_wpe = w2 ? 2 : 1;
+        return launch_lpp<21>(a, w2, stream);
     }
     t_last_lpp = k <= 32 ? 32 : 64;
     const bool w2 = two_per_simd_pays(a, 64 / t_last_lpp);

@@ -15,7 +15,7 @@
 //     term rho|X_0 - x_init + P_H|^2: a diagonal quadratic in X_0.  Lane 0 adds rho to its Q and
 //     2 rho (P_H - x_init) to its q instead of every lane carrying nine extra residual rows.
 //   * momentum coefficients (t_k - 1)/t_{k+1} (fista.cpp:34-35) depend on the iteration index
-//     only; each wave tabulates them once in LDS.
+//     only: one table per device (biconvex_admm.hip: momentum_table), read by scalar loads.
 //   * a problem that finishes (|d| < tol or maxit) has its iterate latched into `fin` registers
 //     at that moment; the loop body itself carries no per-lane freeze selects.
 //
@@ -34,7 +34,6 @@
 template <typename R, int LPP, int E, bool RAW, bool HASQF, bool STEAL = false, bool XLDS = false>
 __device__ __forceinline__ void admm_body(const BatchArgs &a) {
     extern __shared__ double lds_raw[];
-    R *cmtab = reinterpret_cast<R *>(lds_raw);   // [maxit]
     constexpr int NF = 3 * E;           // force variables per knot
     constexpr int NB = RAW ? 9 : 3;     // bounded components per knot
     const int lane = threadIdx.x & 63;
@@ -57,10 +56,10 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
 
     // Iterates at phase boundaries (X, F, P of this segment's problem) live in LDS, each lane touching
     // only its own knot's blocks (lane 0 also the x_init rows of P): HBM sees the inputs once and the
-    // results once.  Layout after the momentum table: some zeros, then per segment [X nx | P nx | F 13 H | R nx].
+    // results once.  Layout: some zeros, then per segment [X nx | P nx | F 13 H | R nx].
     // (F blocks at a stride of NF + 1: at 12 doubles lanes t, t + 8, t + 16 would share their LDS banks)
     constexpr int FS = NF + 1;
-    R *zeros = cmtab + ((maxit + 1) & ~1);        // kLdsZeros zeros: what a lane without a knot reads for x_k (XLDS)
+    R *zeros = reinterpret_cast<R *>(lds_raw);      // kLdsZeros zeros: what a lane without a knot reads for x_k (XLDS)
     R *seg_lds = zeros + kLdsZeros + (long)seg * (3 * nx + (long)FS * H);
     R *Xg = seg_lds + 9L * t;
     R *Pg = seg_lds + nx + 9L * t;
@@ -91,16 +90,9 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
     double *const Xu = a.X + wave0 * nx, *const Fu = a.F + wave0 * nf, *const Pu = a.P + wave0 * nx;
     const double *const xinit_u = a.x_init + wave0 * 9;
 
-    {   // momentum table: t+ = 1 + sqrt(1 + 4 t^2)/2 (sic, fista.cpp:34), c = (t - 1)/t+
-        double tk = 1.0;
-        for (int i = 0; i < maxit; ++i) {
-            const double tk1 = 1.0 + sqrt(1.0 + 4.0 * tk * tk) * 0.5;
-            if (lane == 0) cmtab[i] = (R)((tk - 1.0) / tk1);
-            tk = tk1;
-        }
-        if (lane < kLdsZeros) zeros[lane] = R(0);
-        __syncthreads();
-    }
+    if (lane < kLdsZeros) zeros[lane] = R(0);
+    __syncthreads();
+    const double *const cmtab = a.cmtab;      // (wave-uniform reads: through the scalar cache)
 
     R dt = ldz<R>(a.dt + wave0 * H, oK, 0, rvalid);
     R dtp = from_prev(dt);  // dt of knot t-1 (0 for t == 0: previous lane is a dead/terminal lane)
@@ -244,7 +236,7 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
             // one FISTA iteration: reads x from xo/ro, leaves x_{k+1} in xn/rn, advances y/ry (XLDS: x_k from LDS, x_{k+1} to LDS;
             // the four arrays are then no more than the iteration's temporaries)
             auto iterate = [&](const R (&xo_reg)[NF], const R (&ro_reg)[6], R (&xn)[NF], R (&rn)[6], int i) {
-                const R cm = cmtab[i];
+                const R cm = (R)cmtab[i];
                 R xo[NF], ro[6];
                 if (!XLDS) {
                     UNROLL for (int j = 0; j < NF; ++j) xo[j] = xo_reg[j];
@@ -467,7 +459,7 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
             R invL = R(2) * (R(1) / L_x);
             mask_t act = alive;
             auto iterate = [&](const R (&xo_reg)[9], const R (&ro_reg)[9], R (&xn)[9], R (&rn)[9], int i) {
-                const R cm = cmtab[i];
+                const R cm = (R)cmtab[i];
                 R xo[9], ro[9];
                 if (!XLDS) { UNROLL for (int l = 0; l < 9; ++l) { xo[l] = xo_reg[l]; ro[l] = ro_reg[l]; } }
                 mask_t done;

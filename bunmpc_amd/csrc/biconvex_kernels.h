@@ -48,12 +48,13 @@ struct BatchArgs {
     double *dyn_viol, *hist;
     int *stats;
     int *trace;      // [B][num_iters][4] running totals {it_f, it_x, bt_f, bt_x} after every ADMM iteration, or null
+    const double *cmtab;   // (set by the launcher) FISTA's momentum coefficients (t_k - 1) / t_{k+1}, k = 0 .. kMaxFistaIters - 1: a function of k alone
     int *queue;      // (set by the launcher) the work-stealing kernel's device counter: problems handed out beyond the first per segment
 };
 
 constexpr int kStats = 6;
 constexpr int kLdsZeros = 12;          // zeros in LDS behind the momentum table (biconvex_admm_body.h: lanes without a knot read them)
-constexpr int kMaxFistaIters = 4096;  // momentum table lives in LDS (8 B per iteration): 32 KB + <= 30 KB of iterates < 64 KB
+constexpr int kMaxFistaIters = 4096;  // length of the momentum table (one per device, momentum_table below; the one-problem-per-wave kernel keeps its own in LDS: 32 KB + <= 30 KB of iterates < 64 KB)
 constexpr int kMaxKnots = 64;  // H + 1 <= 64: one knot per lane, one problem per <=64 lanes
 
 // Launch the batched ADMM kernel on `stream`.  Returns hipSuccess or the launch error;
@@ -68,6 +69,7 @@ int set_latency_mapping_max_batch(int max_batch);   // returns the old value
 int set_three_per_wave(int mode);                    // 21-lane segments for 17..21 knots: 0 never, 1 always, 2 when it pays (default); returns the old value
 int set_two_waves_per_simd(int mode);               // the two-waves-per-SIMD build of the fp64 batch kernel: 0 never, 1 always, 2 when it pays (default); returns the old value
 int biconvex_last_waves_per_simd();                  // of the calling host thread's latest launch (1 or 2)
+int set_steal_grid(int waves);                       // waves of the work-stealing kernel's persistent grid (experiments; 0 = what the chip holds); returns the old value
 int set_work_stealing(int on);                       // the segment-level work-stealing kernel for num_iters >= 25 (default on); returns the old value
 int biconvex_last_lanes_per_problem();               // of the calling host thread's latest launch: 16 / 21 / 32 / 64, 0 = one problem per wave
 int set_exact_step_decisions(int on);                // ... takes every step decision from the fp64 sums; returns the old value

@@ -142,6 +142,7 @@ int bmpc_abi_version(void) { return 2; }
 int bmpc_batch_struct_size(void) { return (int)sizeof(bmpc_batch_t); }
 int bmpc_set_three_per_wave(int mode) { return bunmpc::set_three_per_wave(mode); }
 int bmpc_set_work_stealing(int on) { return bunmpc::set_work_stealing(on); }
+int bmpc_set_steal_grid(int waves) { return bunmpc::set_steal_grid(waves); }
 int bmpc_set_two_waves_per_simd(int mode) { return bunmpc::set_two_waves_per_simd(mode); }
 int bmpc_biconvex_last_waves_per_simd(void) { return bunmpc::biconvex_last_waves_per_simd(); }
 int bmpc_biconvex_last_lanes_per_problem(void) { return bunmpc::biconvex_last_lanes_per_problem(); }

@@ -167,6 +167,8 @@ int bmpc_set_three_per_wave(int mode);
  * ("biconvex_admm_steal_kernel"): the batch takes the sum of the problems' iterations over the segments, not the per-wave maxima.
  * A problem's result does not depend on it.  on = 0: never (a test switch).  Default 1.  Returns the old value. */
 int bmpc_set_work_stealing(int on);
+/* waves of that persistent grid (an experiment switch; 0, the default: as many as the chip holds at once).  Returns the old value. */
+int bmpc_set_steal_grid(int waves);
 /* The fp64 batch kernel (16 / 32 / 64 lanes per problem) exists in two builds: for ONE wave per SIMD (FISTA iterates in registers,
  * ~290 of them) and for TWO (256 registers: x_k and its affine image rest in LDS between the iterations; same operations in the
  * same order, bit-identical results).  A lone wave of the second build is the slower one, two of them on a SIMD cover each

@@ -8,8 +8,11 @@ from bunmpc_amd import _lib, batch as bb, problems
 lib = _lib.lib()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 pb = problems.make_batch("solo12_trot", B)
-for name, three, steal in (("two per wave", 0, 0), ("three per wave", 1, 0), ("three per wave + work stealing", 1, 1)):
-    lib.bmpc_set_three_per_wave(three); lib.bmpc_set_work_stealing(steal)
+cases = [("two per wave", 0, 0, 0, 0), ("two per wave, two waves per SIMD", 0, 0, 1, 0), ("three per wave", 1, 0, 0, 0), ("three per wave, two waves per SIMD", 1, 0, 1, 0),
+         ("three per wave + work stealing", 1, 1, 0, 0)]
+cases += [("stealing, two waves per SIMD, grid %d" % g, 1, 1, 1, g) for g in (1024, 1152, 1280, 1366, 1536, 2048)]
+for name, three, steal, w2, grid in cases:
+    lib.bmpc_set_three_per_wave(three); lib.bmpc_set_work_stealing(steal); lib.bmpc_set_two_waves_per_simd(w2); lib.bmpc_set_steal_grid(grid)
     db = bb.DeviceBatch(pb, num_iters=100)
     for _ in range(2):
         db.solve()
@@ -19,5 +22,5 @@ for name, three, steal in (("two per wave", 0, 0), ("three per wave", 1, 0), ("t
         db.solve()
     torch.cuda.synchronize()
     r = db.results()
-    print("%-32s %.2f ms per launch (%s); ADMM iterations sum %d" % (name, (time.perf_counter() - t0) / 5 * 1e3, lib.bmpc_biconvex_last_kernel_name().decode(), r["stats"][:, 0].sum()))
-lib.bmpc_set_three_per_wave(2); lib.bmpc_set_work_stealing(1)
+    print("%-44s %.2f ms per launch (%s); ADMM iterations sum %d" % (name, (time.perf_counter() - t0) / 5 * 1e3, lib.bmpc_biconvex_last_kernel_name().decode(), r["stats"][:, 0].sum()))
+lib.bmpc_set_three_per_wave(2); lib.bmpc_set_work_stealing(1); lib.bmpc_set_two_waves_per_simd(2); lib.bmpc_set_steal_grid(0)
