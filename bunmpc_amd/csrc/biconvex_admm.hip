@@ -84,7 +84,7 @@ template <typename R, int LPP, bool RAW, bool HASQF>
 hipError_t launch(const BatchArgs &a, bool two_per_simd, hipStream_t stream) {
     const int per_wave = 64 / LPP;
     const unsigned grid = (unsigned)((a.B + per_wave - 1) / per_wave);
-    const size_t nstate = 3 * 9 * (size_t)(a.H + 1) + 13 * (size_t)a.H;   // X, P, F (at a stride of 13), R of one problem
+    const size_t nstate = (size_t)kSegLds + (size_t)kKnotLds * (size_t)(a.H + 1);   // X, P, F, R of one problem
     const size_t lds = sizeof(R) * (kLdsZeros + per_wave * nstate);
     if (sizeof(R) == sizeof(float)) return launch_biconvex_admm_f32(a, LPP, grid, lds, stream);      // biconvex_admm_f32.hip
     if (two_per_simd) hipLaunchKernelGGL((biconvex_admm_kernel<double, LPP, 4, RAW, HASQF, 2>), dim3(grid), dim3(64), lds, stream, a);
@@ -139,7 +139,7 @@ hipError_t launch_steal(const BatchArgs &a, long simds, bool two_per_simd, hipSt
     BatchArgs s = a;
     s.queue = steal_counter(stream);
     if (!s.queue) return hipErrorOutOfMemory;
-    const size_t nstate = 3 * 9 * (size_t)(a.H + 1) + 13 * (size_t)a.H;
+    const size_t nstate = (size_t)kSegLds + (size_t)kKnotLds * (size_t)(a.H + 1);
     const size_t lds = sizeof(double) * (kLdsZeros + 3 * nstate);
     const long waves = g_steal_grid > 0 ? std::min<long>(g_steal_grid, (a.B + 2) / 3) : (two_per_simd ? 2 * simds : simds);
     if (two_per_simd) hipLaunchKernelGGL(biconvex_admm_steal_kernel<2>, dim3((unsigned)waves), dim3(64), lds, stream, s);

@@ -56,17 +56,19 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
 
     // Iterates at phase boundaries (X, F, P of this segment's problem) live in LDS, each lane touching
     // only its own knot's blocks (lane 0 also the x_init rows of P): HBM sees the inputs once and the
-    // results once.  Layout: some zeros, then per segment [X nx | P nx | F 13 H | R nx].
-    // (F blocks at a stride of NF + 1: at 12 doubles lanes t, t + 8, t + 16 would share their LDS banks)
-    constexpr int FS = NF + 1;
-    R *zeros = reinterpret_cast<R *>(lds_raw);      // kLdsZeros zeros: what a lane without a knot reads for x_k (XLDS)
-    R *seg_lds = zeros + kLdsZeros + (long)seg * (3 * nx + (long)FS * H);
-    R *Xg = seg_lds + 9L * t;
-    R *Pg = seg_lds + nx + 9L * t;
-    R *PIg = seg_lds + nx + 9L * H;
-    R *Fg = seg_lds + 2 * nx + (long)FS * t;
-    R *Rg = seg_lds + 2 * nx + (long)FS * H + 9L * t;      // XLDS: the affine image of the FISTA loops' x_k
-    const R *Fz = rvalid ? Fg : zeros, *RFz = rvalid ? Rg : zeros, *Xz = kvalid ? Xg : zeros, *RXz = kvalid ? Rg : zeros;
+    // results once.
+    // Layout: kLdsZeros zeros, then per segment the x_init rows' multipliers (kSegLds elements; lane 0 works on them) and one record
+    // per KNOT, [X 9 | P 9 | F NF | R 9] (kKnotLds = 39 elements: an odd stride, no two lanes of a segment share a bank).  Every block
+    // of a lane -- lane 0's x_init block included -- is ONE address (the record's, less kSegLds elements) plus a constant, which the
+    // LDS instructions carry as their immediate offset: one address register per lane instead of one per block (with separate
+    // arrays per block the two-waves build kept reloading five of them from scratch memory).  R: the affine image of the FISTA
+    // loops' x_k (XLDS).
+    static_assert(9 + 9 + NF + 9 == kKnotLds && kSegLds + kKnotLds <= kLdsZeros && kSegLds >= 9, "one LDS record per knot");
+    R *zeros = reinterpret_cast<R *>(lds_raw);      // what a lane without a knot reads for x_k (XLDS)
+    R *Sg = zeros + kLdsZeros + (long)seg * (kSegLds + (long)(H + 1) * kKnotLds) + (long)t * kKnotLds;
+    R *PIg = Sg, *Xg = Sg + kSegLds, *Pg = Xg + 9, *Fg = Xg + 18, *Rg = Xg + 18 + NF;      // (PIg: lane 0's only)
+    const R *Szr = rvalid ? Sg : zeros, *Szk = kvalid ? Sg : zeros;
+    const R *Fz = Szr + kSegLds + 18, *RFz = Szr + kSegLds + 18 + NF, *Xz = Szk + kSegLds, *RXz = Szk + kSegLds + 18 + NF;
     // Global arrays are addressed as a WAVE-UNIFORM base (the block of the wave's first problem: scalar registers) plus a 32-bit
     // per-lane byte offset (problem within the wave, knot): `global_load v, v_off, s[base]`.  A 64-bit pointer per lane and array
     // -- what `a.X + pb * nx + 9 * t` makes -- held some thirty vector registers over both FISTA loops, and they were what the
@@ -78,14 +80,18 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
     const long wave0 = STEAL ? 0L : (long)blockIdx.x * (64 / LPP);
     unsigned sl = STEAL ? (unsigned)(pvalid && prob < a.B ? prob : 0) : (pvalid ? (unsigned)seg : 0u);      // STEAL: the problem index itself
     const unsigned tk = (unsigned)(t <= H ? t : H), tr = (unsigned)(t < H ? t : H - 1);
-    unsigned oX, oPI, oF, oK, oP9;
-    auto set_offsets = [&]() {
-        oX = 8u * (sl * (unsigned)nx + 9u * tk);                  // X, P, Qx, qx, lbx, ubx: [B][9 (H + 1)]
-        oPI = 8u * (sl * (unsigned)nx + 9u * (unsigned)H);
-        oF = 8u * (sl * (unsigned)nf + (unsigned)NF * tr);        // F, Qf, qf: [B][3 E H]
-        oK = 8u * (sl * (unsigned)H + tr);                        // dt: [B][H]; cnt_plan: E * 4 doubles per entry
-        oP9 = 8u * 9u * sl;                                        // x_init, X_ter: [B][9]
+    struct Off { unsigned X, PI, F, K, P9; };
+    auto make_off = [&](unsigned slv) {
+        Off o;
+        o.X = 8u * (slv * (unsigned)nx + 9u * tk);                  // X, P, Qx, qx, lbx, ubx: [B][9 (H + 1)]
+        o.PI = 8u * (slv * (unsigned)nx + 9u * (unsigned)H);
+        o.F = 8u * (slv * (unsigned)nf + (unsigned)NF * tr);        // F, Qf, qf: [B][3 E H]
+        o.K = 8u * (slv * (unsigned)H + tr);                        // dt: [B][H]; cnt_plan: E * 4 doubles per entry
+        o.P9 = 8u * 9u * slv;                                        // x_init, X_ter: [B][9]
+        return o;
     };
+    unsigned oX, oPI, oF, oK, oP9;
+    auto set_offsets = [&]() { const Off o = make_off(sl); oX = o.X; oPI = o.PI; oF = o.F; oK = o.K; oP9 = o.P9; };
     set_offsets();
     double *const Xu = a.X + wave0 * nx, *const Fu = a.F + wave0 * nf, *const Pu = a.P + wave0 * nx;
     const double *const xinit_u = a.x_init + wave0 * 9;
@@ -173,11 +179,15 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
         // contact data of this knot: flags c_n, positions r_n  (centroidal.cpp:39-49); re-read in
         // each phase (L2-resident) rather than held in registers across the FISTA loops
         const double *const cnt_u = a.cnt_plan + wave0 * H * (E * 4);
-        const unsigned oC = oK * (unsigned)(E * 4);
 
         // =================================================================== F step
         {
             const unsigned ph = opaque_zero();      // see opaque_zero (biconvex_lanes.h): the inputs are re-read in each phase
+            // XLDS: ... and their offsets re-made from the problem's index (hoisted out of the ADMM loop they were a dozen registers
+            // that the 256-register build kept in scratch memory)
+            const unsigned sl_ = XLDS ? opaque_copy(sl) : sl;
+            const Off o = XLDS ? make_off(sl_) : Off{oX, oPI, oF, oK, oP9};
+            const unsigned oC = o.K * (unsigned)(E * 4);
             R c[E], r[E][3];
             UNROLL for (int n = 0; n < E; ++n) {
                 c[n] = ldz<R>(cnt_u, oC + ph, 4 * n, rvalid);
@@ -204,9 +214,9 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
             // y - g/L, and the doubled copies of the weights (2 Q, 2 rho) need no registers.
             R wf[NF], qf[HASQF ? NF : 1];
             UNROLL for (int j = 0; j < NF; ++j) {
-                wf[j] = RAW ? ldz<R>(a.Qf + wave0 * nf, oF + ph, j, rvalid)
-                            : ldz<R>(a.W_F + wave0 * a.sW_F, 8u * (sl * (unsigned)a.sW_F + (unsigned)NF * tr) + ph, j, rvalid);
-                if (HASQF) qf[j] = R(0.5) * ldz<R>(a.qf + wave0 * nf, oF + ph, j, rvalid);
+                wf[j] = RAW ? ldz<R>(a.Qf + wave0 * nf, o.F + ph, j, rvalid)
+                            : ldz<R>(a.W_F + wave0 * a.sW_F, 8u * (sl_ * (unsigned)a.sW_F + (unsigned)NF * tr) + ph, j, rvalid);
+                if (HASQF) qf[j] = R(0.5) * ldz<R>(a.qf + wave0 * nf, o.F + ph, j, rvalid);
             }
             // u = A v + bPk on rows 9t+3..8
             auto applyA = [&](const R (&v)[NF], R (&u)[6]) {
@@ -361,6 +371,9 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
         // =================================================================== X step
         {
             const unsigned ph = opaque_zero();
+            const unsigned sl_ = XLDS ? opaque_copy(sl) : sl;
+            const Off o = XLDS ? make_off(sl_) : Off{oX, oPI, oF, oK, oP9};
+            const unsigned oC = o.K * (unsigned)(E * 4);
             R c[E], r[E][3];
             UNROLL for (int n = 0; n < E; ++n) {
                 c[n] = ldz<R>(cnt_u, oC + ph, 4 * n, rvalid);
@@ -389,21 +402,21 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
             R qd[9], q[9], lb[NB], ub[NB];
             if (RAW) {
                 UNROLL for (int l = 0; l < 9; ++l) {
-                    qd[l] = ldz<R>(a.Qx + wave0 * nx, oX + ph, l, kvalid);
-                    q[l] = R(0.5) * ldz<R>(a.qx + wave0 * nx, oX + ph, l, kvalid);     // q/2
+                    qd[l] = ldz<R>(a.Qx + wave0 * nx, o.X + ph, l, kvalid);
+                    q[l] = R(0.5) * ldz<R>(a.qx + wave0 * nx, o.X + ph, l, kvalid);     // q/2
                 }
                 UNROLL for (int l = 0; l < NB; ++l) {
-                    const R lo = (R)at(a.lbx + wave0 * nx, oX + ph)[l], hi = (R)at(a.ubx + wave0 * nx, oX + ph)[l];
+                    const R lo = (R)at(a.lbx + wave0 * nx, o.X + ph)[l], hi = (R)at(a.ubx + wave0 * nx, o.X + ph)[l];
                     lb[l] = kvalid ? lo : R(-INFINITY);
                     ub[l] = kvalid ? hi : R(INFINITY);
                 }
             } else {
                 // create_cost_X (biconvex.cpp:57-72)
                 UNROLL for (int l = 0; l < 9; ++l) {
-                    const double w_run = at(a.W_X + wave0 * a.sW_X, 8u * (sl * (unsigned)a.sW_X + 9u * tr) + ph)[l];
-                    const double w_ter = at(a.W_X_ter + wave0 * a.sW_X_ter, 8u * sl * (unsigned)a.sW_X_ter + ph)[l];
-                    const double x_run = at(a.X_nom + wave0 * 9L * H, 8u * 9u * (sl * (unsigned)H + tr) + ph)[l];
-                    const double x_ter = at(a.X_ter + wave0 * 9, oP9 + ph)[l];
+                    const double w_run = at(a.W_X + wave0 * a.sW_X, 8u * (sl_ * (unsigned)a.sW_X + 9u * tr) + ph)[l];
+                    const double w_ter = at(a.W_X_ter + wave0 * a.sW_X_ter, 8u * sl_ * (unsigned)a.sW_X_ter + ph)[l];
+                    const double x_run = at(a.X_nom + wave0 * 9L * H, 8u * 9u * (sl_ * (unsigned)H + tr) + ph)[l];
+                    const double x_ter = at(a.X_ter + wave0 * 9, o.P9 + ph)[l];
                     const R w = (R)(rvalid ? w_run : (kvalid ? w_ter : 0.0));
                     const R xr = (R)(rvalid ? x_run : (kvalid ? x_ter : 0.0));
                     qd[l] = w;
@@ -416,7 +429,7 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
                 UNROLL for (int k = 0; k < 3; ++k) {
                     R mx = r[0][k], mn = r[0][k];
                     UNROLL for (int n = 1; n < E; ++n) { mx = fmaxR(mx, r[n][k]); mn = fminR(mn, r[n][k]); }
-                    const double *bnd = at(a.bounds + wave0 * a.sbounds, 8u * (sl * (unsigned)a.sbounds + 6u * tr) + ph);
+                    const double *bnd = at(a.bounds + wave0 * a.sbounds, 8u * (sl_ * (unsigned)a.sbounds + 6u * tr) + ph);
                     const double b_lo = bnd[k], b_hi = bnd[3 + k];
                     const R blo = (R)(bounded ? b_lo : 0.0);
                     const R bhi = (R)(bounded ? b_hi : 0.0);
@@ -426,9 +439,12 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
             }
             // x_init rows folded into lane 0's diagonal cost:  rho |X_0 + (P_H - x_init)|^2   (q holds q/2: half-gradient form,
             // see the force step)
+            R pi[9];
+            UNROLL for (int l = 0; l < 9; ++l) pi[l] = R(0);
+            if (l0) { UNROLL for (int l = 0; l < 9; ++l) pi[l] = PIg[l]; }
             UNROLL for (int l = 0; l < 9; ++l) {
-                const R xi = (R)at(xinit_u, oP9 + ph)[l];
-                const R bpi = l0 ? (PIg[l] - xi) : R(0);
+                const R xi = (R)at(xinit_u, o.P9 + ph)[l];
+                const R bpi = l0 ? (pi[l] - xi) : R(0);
                 qd[l] += l0 ? rho : R(0);
                 q[l] = fmaR(rho, bpi, q[l]);
             }
@@ -544,14 +560,16 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
                 w[7] += SZ * fin[0] - SX * fin[2];
                 w[8] += SX * fin[1] - SY * fin[0];
                 const bool al = lanes(alive);
+                R dr[9], dx0[9];
                 UNROLL for (int l = 0; l < 9; ++l) {
                     const R d = rvalid ? (w[l] - bf[l]) : R(0);
-                    const R xi = (R)at(xinit_u, oP9 + ph)[l];
+                    const R xi = (R)at(xinit_u, o.P9 + ph)[l];
                     const R di = l0 ? (fin[l] - xi) : R(0);
-                    if (al && rvalid) Pg[l] += d;
-                    if (al && l0) PIg[l] += di;
+                    dr[l] = d; dx0[l] = di;
                     v2 += (double)d * (double)d + (double)di * (double)di;
                 }
+                if (al && rvalid) { UNROLL for (int l = 0; l < 9; ++l) Pg[l] += dr[l]; }
+                if (al && l0) { UNROLL for (int l = 0; l < 9; ++l) PIg[l] += dx0[l]; }
             }
             v2 = seg_sum<LPP>(v2);
             const double nrm = sqrt(v2);
@@ -559,10 +577,10 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
                 last_viol = nrm;
                 const unsigned row = STEAL ? (unsigned)n_admm : (unsigned)it;      // the ADMM iteration this was, counted per problem
                 ++n_admm;
-                if (a.hist && l0) *at(a.hist + wave0 * a.c.num_iters, 8u * (sl * (unsigned)a.c.num_iters + row)) = nrm;
+                if (a.hist && l0) *at(a.hist + wave0 * a.c.num_iters, 8u * (sl_ * (unsigned)a.c.num_iters + row)) = nrm;
 #ifndef BMPC_NO_TRACE
                 if (a.trace && l0) {
-                    int *tr = a.trace + ((wave0 + sl) * a.c.num_iters + row) * 4;
+                    int *tr = a.trace + ((wave0 + sl_) * a.c.num_iters + row) * 4;
                     tr[0] = it_f; tr[1] = it_x; tr[2] = bt_f; tr[3] = bt_x;
                 }
 #endif

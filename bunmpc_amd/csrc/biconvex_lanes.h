@@ -179,6 +179,8 @@ __device__ __forceinline__ double *at(double *ubase, unsigned byte_off) {
 // during a solve, so with plain offsets hipcc hoists the LOADED VALUES (weights, contact plan, bounds: ~60 registers) out of the
 // ADMM loop and carries them across both FISTA loops; re-reading them in each of the ten ADMM iterations (L2-resident) is free.
 __device__ __forceinline__ unsigned opaque_zero() { unsigned z = 0; asm volatile("" : "+v"(z)); return z; }
+// v, as a value the optimiser knows nothing about (no instruction): what is computed from it stays where it is written
+__device__ __forceinline__ unsigned opaque_copy(unsigned v) { asm volatile("" : "+v"(v)); return v; }
 // a use of v the optimiser cannot move or remove (no instruction)
 __device__ __forceinline__ void keep_here(double &v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void keep_here(float &v) { asm volatile("" : "+v"(v)); }
