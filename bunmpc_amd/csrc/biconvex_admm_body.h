@@ -108,6 +108,18 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
     R L_x, L_f;
     int n_admm = 0, it_f = 0, it_x = 0, bt_f = 0, bt_x = 0, status = 0;
     double last_viol = 0.0;
+    // XLDS: the bookkeeping of a problem -- step constants, counters, the last violation: segment-uniform values every lane carries --
+    // is in registers only during the phase that changes it; across the OTHER phase's FISTA loop it rests in the problem's LDS
+    // header (behind the x_init block; lane 0 writes, every lane of the segment reads the same words back).  In registers throughout
+    // they were what the 256-register build stored to scratch memory in every ADMM iteration.
+    static_assert(!XLDS || sizeof(R) == sizeof(double), "the LDS header holds doubles");
+    double *const Hd = reinterpret_cast<double *>(zeros) + kLdsZeros + (long)(seg < 64 / LPP ? seg : 0) * (kSegLds + (long)(H + 1) * kKnotLds);
+    int *const Hi = reinterpret_cast<int *>(Hd + 12);
+    auto lds_fence = [&]() { asm volatile("" ::: "memory"); };       // (the compiler may not carry a parked value past this in a register)
+    auto park_x = [&]() { if (l0) { Hd[9] = (double)L_x; Hd[11] = last_viol; Hi[0] = it_x; Hi[1] = bt_x; Hi[2] = n_admm; Hi[3] = status; } lds_fence(); };
+    auto load_x = [&]() { lds_fence(); L_x = (R)Hd[9]; last_viol = Hd[11]; it_x = Hi[0]; bt_x = Hi[1]; n_admm = Hi[2]; status = Hi[3]; };
+    auto park_f = [&]() { if (l0) { Hd[10] = (double)L_f; Hi[4] = it_f; Hi[5] = bt_f; } lds_fence(); };
+    auto load_f = [&]() { lds_fence(); L_f = (R)Hd[10]; it_f = Hi[4]; bt_f = Hi[5]; };
     // the problem `sl` names (every offset set) comes on chip: step constants, iterates, counters (lanes of the segments in m)
     auto load_problem = [&](mask_t m) {
         const bool on = lanes(m);
@@ -182,6 +194,7 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
 
         // =================================================================== F step
         {
+            if (XLDS) park_x();
             const unsigned ph = opaque_zero();      // see opaque_zero (biconvex_lanes.h): the inputs are re-read in each phase
             // XLDS: ... and their offsets re-made from the problem's index (hoisted out of the ADMM loop they were a dozen registers
             // that the 256-register build kept in scratch memory)
@@ -370,6 +383,7 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
 
         // =================================================================== X step
         {
+            if (XLDS) { load_x(); park_f(); }
             const unsigned ph = opaque_zero();
             const unsigned sl_ = XLDS ? opaque_copy(sl) : sl;
             const Off o = XLDS ? make_off(sl_) : Off{oX, oPI, oF, oK, oP9};
@@ -381,21 +395,23 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
             }
             // A_f / b_f entries of this knot from the new forces (centroidal.cpp:86-127)
             R SX = 0, SY = 0, SZ = 0, bf[9];
-            {
+            auto make_bf = [&](const R (&cc)[E], const R (&rr)[E][3], R (&b)[9], R &sx, R &sy, R &sz) {
                 R b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0, b8 = 0;
+                sx = 0; sy = 0; sz = 0;
                 UNROLL for (int n = 0; n < E; ++n) {
                     const R fx = rvalid ? Fg[3 * n] : R(0), fy = rvalid ? Fg[3 * n + 1] : R(0),
                             fz = rvalid ? Fg[3 * n + 2] : R(0);
-                    SX += c[n] * fx * dt; SY += c[n] * fy * dt; SZ += c[n] * fz * dt;
-                    b3 += -c[n] * fx * dt / m; b4 += -c[n] * fy * dt / m; b5 += -c[n] * fz * dt / m;
-                    b6 += (c[n] * fy * r[n][2] - c[n] * fz * r[n][1]) * dt;
-                    b7 += (c[n] * fz * r[n][0] - c[n] * fx * r[n][2]) * dt;
-                    b8 += (c[n] * fx * r[n][1] - c[n] * fy * r[n][0]) * dt;
+                    sx += cc[n] * fx * dt; sy += cc[n] * fy * dt; sz += cc[n] * fz * dt;
+                    b3 += -cc[n] * fx * dt / m; b4 += -cc[n] * fy * dt / m; b5 += -cc[n] * fz * dt / m;
+                    b6 += (cc[n] * fy * rr[n][2] - cc[n] * fz * rr[n][1]) * dt;
+                    b7 += (cc[n] * fz * rr[n][0] - cc[n] * fx * rr[n][2]) * dt;
+                    b8 += (cc[n] * fx * rr[n][1] - cc[n] * fy * rr[n][0]) * dt;
                 }
-                bf[0] = 0; bf[1] = 0; bf[2] = 0;
-                bf[3] = b3; bf[4] = b4; bf[5] = b5 + R(kGravity) * dt;
-                bf[6] = b6; bf[7] = b7; bf[8] = b8;
-            }
+                b[0] = 0; b[1] = 0; b[2] = 0;
+                b[3] = b3; b[4] = b4; b[5] = b5 + R(kGravity) * dt;
+                b[6] = b6; b[7] = b7; b[8] = b8;
+            };
+            make_bf(c, r, bf, SX, SY, SZ);
             R bpk[9];
             UNROLL for (int l = 0; l < 9; ++l) bpk[l] = rvalid ? (-bf[l] + Pg[l]) : R(0);
             // cost and bounds of this knot
@@ -548,6 +564,17 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
             }
             R fin[9];
             UNROLL for (int l = 0; l < 9; ++l) fin[l] = kvalid ? Xg[l] : R(0);
+            if (XLDS) load_f();
+            if (XLDS) {     // b_f made again from the contact plan and the forces (same expressions, same bits) instead of six registers held
+                            // across the FISTA loop -- which the 256-register build held in scratch memory
+                const unsigned ph2 = opaque_zero();
+                R c2[E], r2[E][3], s0, s1, s2;
+                UNROLL for (int n = 0; n < E; ++n) {
+                    c2[n] = ldz<R>(cnt_u, oC + ph2, 4 * n, rvalid);
+                    UNROLL for (int k = 0; k < 3; ++k) r2[n][k] = ldz<R>(cnt_u, oC + ph2, 4 * n + 1 + k, rvalid);
+                }
+                make_bf(c2, r2, bf, s0, s1, s2);
+            }
 
             // dyn_violation = A_f X - b_f ; P += dyn_violation          (biconvex.cpp:98-99)
             double v2 = 0;   // the dynamics violation is accumulated in fp64 whatever R is

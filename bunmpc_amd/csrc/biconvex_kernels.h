@@ -54,8 +54,8 @@ struct BatchArgs {
 
 constexpr int kStats = 6;
 constexpr int kKnotLds = 39;           // LDS elements per knot of a problem (biconvex_admm_body.h: X 9, P 9, F 12, R 9)
-constexpr int kSegLds = 10;            // ... and per problem in front of its knots (the x_init rows' multipliers, 9)
-constexpr int kLdsZeros = 50;          // zeros in LDS in front of all that (lanes without a knot read them)
+constexpr int kSegLds = 15;            // ... and per problem in front of its knots (the x_init rows' multipliers, 9; XLDS: step constants, violation, counters)
+constexpr int kLdsZeros = 54;          // zeros in LDS in front of all that (lanes without a knot read them)
 constexpr int kMaxFistaIters = 4096;  // length of the momentum table (one per device, momentum_table below; the one-problem-per-wave kernel keeps its own in LDS: 32 KB + <= 30 KB of iterates < 64 KB)
 constexpr int kMaxKnots = 64;  // H + 1 <= 64: one knot per lane, one problem per <=64 lanes
 
