@@ -113,13 +113,32 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
     // header (behind the x_init block; lane 0 writes, every lane of the segment reads the same words back).  In registers throughout
     // they were what the 256-register build stored to scratch memory in every ADMM iteration.
     static_assert(!XLDS || sizeof(R) == sizeof(double), "the LDS header holds doubles");
-    double *const Hd = reinterpret_cast<double *>(zeros) + kLdsZeros + (long)(seg < 64 / LPP ? seg : 0) * (kSegLds + (long)(H + 1) * kKnotLds);
-    int *const Hi = reinterpret_cast<int *>(Hd + 12);
+    // (the header's address is made where it is used, from the lane number as a value the optimiser cannot trace: hoisted out of
+    // the ADMM loop it was itself kept in scratch memory)
+    auto header = [&]() {
+        const int sg = (int)(opaque_copy((unsigned)lane) / (unsigned)LPP);
+        return reinterpret_cast<double *>(zeros) + kLdsZeros + (long)(sg < 64 / LPP ? sg : 0) * (kSegLds + (long)(H + 1) * kKnotLds);
+    };
     auto lds_fence = [&]() { asm volatile("" ::: "memory"); };       // (the compiler may not carry a parked value past this in a register)
-    auto park_x = [&]() { if (l0) { Hd[9] = (double)L_x; Hd[11] = last_viol; Hi[0] = it_x; Hi[1] = bt_x; Hi[2] = n_admm; Hi[3] = status; } lds_fence(); };
-    auto load_x = [&]() { lds_fence(); L_x = (R)Hd[9]; last_viol = Hd[11]; it_x = Hi[0]; bt_x = Hi[1]; n_admm = Hi[2]; status = Hi[3]; };
-    auto park_f = [&]() { if (l0) { Hd[10] = (double)L_f; Hi[4] = it_f; Hi[5] = bt_f; } lds_fence(); };
-    auto load_f = [&]() { lds_fence(); L_f = (R)Hd[10]; it_f = Hi[4]; bt_f = Hi[5]; };
+    auto park_x = [&]() {      // before the force loop: everything the motion step and the end of the ADMM iteration work on
+        if (l0) { double *Hd = reinterpret_cast<double *>(Sg); int *Hi = reinterpret_cast<int *>(Hd + 12);      // (lane 0's record starts at the header)
+                  Hd[9] = (double)L_x; Hd[11] = last_viol; Hi[0] = it_x; Hi[1] = bt_x; Hi[2] = n_admm; Hi[3] = status; }
+        lds_fence();
+    };
+    auto park_f = [&]() {      // before the motion step: what the force loop works on
+        if (l0) { double *Hd = reinterpret_cast<double *>(Sg); int *Hi = reinterpret_cast<int *>(Hd + 12); Hd[10] = (double)L_f; Hi[4] = it_f; Hi[5] = bt_f; }
+        lds_fence();
+    };
+    auto load_xloop = [&]() {      // in front of the motion loop
+        lds_fence();
+        const double *Hd = header(); const int *Hi = reinterpret_cast<const int *>(Hd + 12);
+        L_x = (R)Hd[9]; it_x = Hi[0]; bt_x = Hi[1];
+    };
+    auto load_rest = [&]() {       // behind it: the end of the ADMM iteration reads and updates all of it
+        lds_fence();
+        const double *Hd = header(); const int *Hi = reinterpret_cast<const int *>(Hd + 12);
+        last_viol = Hd[11]; n_admm = Hi[2]; status = Hi[3]; L_f = (R)Hd[10]; it_f = Hi[4]; bt_f = Hi[5];
+    };
     // the problem `sl` names (every offset set) comes on chip: step constants, iterates, counters (lanes of the segments in m)
     auto load_problem = [&](mask_t m) {
         const bool on = lanes(m);
@@ -383,7 +402,7 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
 
         // =================================================================== X step
         {
-            if (XLDS) { load_x(); park_f(); }
+            if (XLDS) park_f();
             const unsigned ph = opaque_zero();
             const unsigned sl_ = XLDS ? opaque_copy(sl) : sl;
             const Off o = XLDS ? make_off(sl_) : Off{oX, oPI, oF, oK, oP9};
@@ -488,6 +507,7 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
             UNROLL for (int l = 0; l < 9; ++l) ra[l] = ry[l];
             if (XLDS && kvalid) { UNROLL for (int l = 0; l < 9; ++l) Rg[l] = ry[l]; }
             const double tol2 = tol * tol;
+            if (XLDS) load_xloop();
             R invL = R(2) * (R(1) / L_x);
             mask_t act = alive;
             auto iterate = [&](const R (&xo_reg)[9], const R (&ro_reg)[9], R (&xn)[9], R (&rn)[9], int i) {
@@ -564,7 +584,7 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
             }
             R fin[9];
             UNROLL for (int l = 0; l < 9; ++l) fin[l] = kvalid ? Xg[l] : R(0);
-            if (XLDS) load_f();
+            if (XLDS) load_rest();
             if (XLDS) {     // b_f made again from the contact plan and the forces (same expressions, same bits) instead of six registers held
                             // across the FISTA loop -- which the 256-register build held in scratch memory
                 const unsigned ph2 = opaque_zero();

@@ -19,7 +19,7 @@ with open("profiles/%s_bench_kernel_stats.csv" % rnd, "w") as f:
     w.writeheader()
     w.writerows(keep)
 trace = list(csv.DictReader(open(newest("gpurun_out/prof_%s/**/*kernel_trace.csv" % tag))))
-name = "biconvex_admm_kernel<double, 32, 4, false, false>"
+name = "biconvex_admm_kernel<double, 32, 4, false, false, 2>"      # (the two-waves-per-SIMD build: what the dispatch takes at B = 4096)
 h = sorted((r for r in trace if name in r["Kernel_Name"] and int(r["Grid_Size_X"]) == 2048 * 64), key=lambda r: int(r["Start_Timestamp"]))
 n_warm, n_timed = bench["warmup"], bench["steps"]
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in h]
@@ -59,7 +59,7 @@ for w, key in keys.items():
                     "note": "sums over all launches of one batch solve (3 solves measured, divided by 3); FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950"}
     if w == "biconvex":
         k0 = [k for k in kern if "biconvex" in k][0]
-        traffic[key].update(kernel="biconvex_admm_kernel<double, 32, 4, false, false>", algorithmic_bytes=37912576, traffic_bytes=kern[k0]["traffic_bytes"],
+        traffic[key].update(kernel="biconvex_admm_kernel<double, 32, 4, false, false, 2>", algorithmic_bytes=37912576, traffic_bytes=kern[k0]["traffic_bytes"],
                             fetch_size_kb_raw=kern[k0]["fetch_size_kb_raw"], write_size_kb=kern[k0]["write_size_kb"])
     lines.append("%-12s TOTAL traffic per batch solve: %.1f MB" % (w, traffic[key]["traffic_bytes"] / 1e6))
 open("profiles/%s_pmc_hbm.txt" % rnd, "w").write("\n".join(lines) + "\n")
