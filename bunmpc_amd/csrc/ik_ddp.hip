@@ -165,6 +165,20 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // ------------------------------------------------------------------------------- init ---
+// The robot model into LDS, by all threads of the workgroup: eight words per thread in flight (one by one, each load was waited
+// for before its LDS write: 6 .. 18 round trips to L2 in front of a kernel's first node)
+template <int THREADS>
+__device__ __forceinline__ void stage_model(const RobotModelDev *model, RobotModelDev *lds) {
+    constexpr int kWords = (int)(sizeof(RobotModelDev) / sizeof(int));
+    const int *src = reinterpret_cast<const int *>(model);
+    int *dst = reinterpret_cast<int *>(lds);
+    for (int i0 = threadIdx.x; i0 < kWords; i0 += 8 * THREADS) {
+        int v[8];
+        UNROLL_RBD for (int k = 0; k < 8; ++k) { const int i = i0 + k * THREADS; v[k] = src[i < kWords ? i : kWords - 1]; }
+        UNROLL_RBD for (int k = 0; k < 8; ++k) { const int i = i0 + k * THREADS; if (i < kWords) dst[i] = v[k]; }
+    }
+}
+
 __global__ void ik_init_kernel(const IkBatchArgs a) {
     const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= a.B) return;
@@ -542,9 +556,7 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff_kernel(const IkBatchArgs a
     long long pc[6] = {0, 0, 0, 0, 0, 0}, pt0 = __builtin_readcyclecounter();
 #endif
     {
-        const int *src = reinterpret_cast<const int *>(a.model);
-        int *dst = reinterpret_cast<int *>(&s.m);
-        for (int i = threadIdx.x; i < (int)(sizeof(RobotModelDev) / sizeof(int)); i += 128) dst[i] = src[i];
+        stage_model<128>(a.model, &s.m);
     }
     const RobotModelDev &m = s.m;
     const double *state_w0 = batch_ptr(a.state_w, a.s_state_w, b), *ctrl_w0 = batch_ptr(a.ctrl_w, a.s_ctrl_w, b);
@@ -605,9 +617,7 @@ __global__ __launch_bounds__(128, 2) void ik_calcdiff1_kernel(const IkBatchArgs 
     const int nn = a.T + 1, groups = (nn + kCalcNodes - 1) / kCalcNodes;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     {
-        const int *src = reinterpret_cast<const int *>(a.model);
-        int *dst = reinterpret_cast<int *>(&s.m);
-        for (int i = threadIdx.x; i < (int)(sizeof(RobotModelDev) / sizeof(int)); i += 128) dst[i] = src[i];
+        stage_model<128>(a.model, &s.m);
         if (threadIdx.x == 0) s.args = a;
     }
     __syncthreads();        // (the only workgroup barrier: from here on the two waves have nothing to do with each other)
@@ -1485,9 +1495,7 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
     const int tslot = spec ? 4 * grp + si : 0;       // where this sub-group's trial trajectory goes
     const long xs_try = L.xs_try + (long)tslot * nn * kNX, us_try = L.us_try + (long)tslot * T * kNV;
     if (!FUSED) {   // the robot model is read many times per node: stage it in LDS once (the fused kernel did, when it started)
-        const int *src = reinterpret_cast<const int *>(a.model);
-        int *dst = reinterpret_cast<int *>(&s.m);
-        for (int i = threadIdx.x; i < (int)(sizeof(RobotModelDev) / sizeof(int)); i += 64 * NW) dst[i] = src[i];
+        stage_model<64 * NW>(a.model, &s.m);
     }
     const double *gsw = batch_ptr(a.state_w, a.s_state_w, bb), *gcw = batch_ptr(a.ctrl_w, a.s_ctrl_w, bb), *gxr = a.x_reg + bb * a.s_x_reg;
     const bool per_node = (a.sn_state_w | a.sn_x_reg | a.sn_ctrl_w) != 0;    // time-varying regularisation (acyclic plans)
@@ -1496,7 +1504,14 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
         for (int i = l; i < kNDX; i += kFwdLanes) q.sw[i] = gsw[a.sn_state_w * t + i];
         if (t < a.T || a.sn_ctrl_w == 0) { for (int i = l; i < kNV; i += kFwdLanes) q.cw[i] = gcw[a.sn_ctrl_w * t + i]; }
     };
-    if (live && do_chain) stage_reg(0);
+    if (live && do_chain) {      // node 0's: all of a lane's loads in flight together (stage_reg's loops wait for each load in turn: eight round trips in front of the first node)
+        static_assert(kNX <= 3 * kFwdLanes && kNDX <= 3 * kFwdLanes && kNV <= 2 * kFwdLanes, "up to three elements per lane and array");
+        double vx[3], vs[3], vc[2];
+        UNROLL_RBD for (int k = 0; k < 3; ++k) { const int i = l + kFwdLanes * k; vx[k] = gxr[i < kNX ? i : kNX - 1]; vs[k] = gsw[i < kNDX ? i : kNDX - 1]; }
+        UNROLL_RBD for (int k = 0; k < 2; ++k) { const int i = l + kFwdLanes * k; vc[k] = gcw[i < kNV ? i : kNV - 1]; }
+        UNROLL_RBD for (int k = 0; k < 3; ++k) { const int i = l + kFwdLanes * k; if (i < kNX) q.xreg[i] = vx[k]; if (i < kNDX) q.sw[i] = vs[k]; }
+        UNROLL_RBD for (int k = 0; k < 2; ++k) { const int i = l + kFwdLanes * k; if (i < kNV) q.cw[i] = vc[k]; }
+    }
     fwd_sync<NW>();
     const RobotModelDev &m = s.m;
     const double *state_w = q.sw, *ctrl_w = q.cw, *x_reg = q.xreg;
@@ -1520,9 +1535,17 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
         double ctry = 0.0;
         if (run && do_chain) {
             if (per_node && round > 0) stage_reg(0);
-            for (int i = l; i < kNX; i += kFwdLanes) { q.x[0][i] = ws[L.xs_try + i]; q.xs[i] = ws[L.xs + i]; }   // x0 sits in slot 0
-            for (int i = l; i < kNodeTaskDoubles; i += kFwdLanes) q.tk[0][i] = gtasks[i];
-            if (l == 0) q.tk[0][kNodeTaskDoubles] = gdt[0];
+            double v0[3], v1[3], v2[3];      // x0 (it sits in trial slot 0), the nominal x0, node 0's task block with its dt behind it
+            UNROLL_RBD for (int k = 0; k < 3; ++k) {
+                const int i = l + kFwdLanes * k, ix = i < kNX ? i : kNX - 1;
+                v0[k] = ws[L.xs_try + ix]; v1[k] = ws[L.xs + ix];
+                v2[k] = i < kNodeTaskDoubles ? gtasks[i] : gdt[0];
+            }
+            UNROLL_RBD for (int k = 0; k < 3; ++k) {
+                const int i = l + kFwdLanes * k;
+                if (i < kNX) { q.x[0][i] = v0[k]; q.xs[i] = v1[k]; }
+                if (i <= kNodeTaskDoubles) q.tk[0][i] = v2[k];
+            }
         }
         // feedback rows of node 0 (lanes 0..8 own rows l and l + 9): fetched one node ahead of their use from here on
         double kp0[kNDX], kp1[kNDX], up0 = 0.0, up1 = 0.0, fp0 = 0.0, fp1 = 0.0;
@@ -1745,7 +1768,9 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
             __threadfence();
             if (threadIdx.x == 0) *arrive = 0u;
             int w = -1;
-            for (int k = 9; k >= 0; --k) if (__builtin_nontemporal_load(ws + L.votes + 2 * k) != 0.0) w = k;    // first in SolverDDP's order
+            double vv[10];      // (the ten votes requested together: read in the loop below, each was waited for before the next was asked for)
+            UNROLL_RBD for (int k = 0; k < 10; ++k) vv[k] = __builtin_nontemporal_load(ws + L.votes + 2 * k);
+            UNROLL_RBD for (int k = 9; k >= 0; --k) if (vv[k] != 0.0) w = k;    // first in SolverDDP's order
             if (live) {
                 if (w >= 0) { accepted = true; win = w; alpha = ldexp(1.0, -w); cost_try = __builtin_nontemporal_load(ws + L.votes + 2 * w + 1); }
                 else alpha = ldexp(1.0, -9);
@@ -1775,9 +1800,18 @@ __device__ __forceinline__ void forward_body(const IkBatchArgs &a, ForwardLds &s
     double xreg = sc[S_XREG];
     if (accepted) {   // setCandidate(xs_try, us_try, true)
         const long xsrc = L.xs_try + (long)win * nn * kNX, usrc = L.us_try + (long)win * T * kNV;
+        // (eight elements per lane in flight: one by one, each load was waited for before its store -- 38 round trips to the
+        // workspace per accepted step of the four-problems-per-wave mapping)
         const int i0 = spec ? lane : l, step = spec ? 64 : kFwdLanes;
-        for (long i = i0; i < (long)nn * kNX; i += step) ws[L.xs + i] = i < kNX ? ws[L.xs_try + i] : ws[xsrc + i];
-        for (long i = i0; i < (long)T * kNV; i += step) ws[L.us + i] = ws[usrc + i];
+        auto copy8 = [&](long dst, long src, long src0, long n0, long n) {      // ws[dst + i] = ws[(i < n0 ? src0 : src) + i], i = i0, i0 + step, ... < n
+            for (long i = i0; i < n; i += 8L * step) {
+                double v[8];
+                UNROLL_RBD for (int k = 0; k < 8; ++k) { long j = i + (long)k * step; j = j < n ? j : n - 1; v[k] = ws[(j < n0 ? src0 : src) + j]; }      // (unconditional: a lane past the end reads the last element)
+                UNROLL_RBD for (int k = 0; k < 8; ++k) { const long j = i + (long)k * step; if (j < n) ws[dst + j] = v[k]; }
+            }
+        };
+        copy8(L.xs, xsrc, L.xs_try, kNX, (long)nn * kNX);
+        copy8(L.us, usrc, usrc, 0, (long)T * kNV);
     }
     if (alpha > 0.5) xreg = fmax(xreg / 10.0, 1e-9);          // decreaseRegularization
     bool done = false;
@@ -1993,9 +2027,7 @@ __global__ __launch_bounds__(256) void ik_fused_kernel(const IkBatchArgs a, cons
     double *ws = a.ws + b * L.total;
     double *sc = ws + L.scal;
     {
-        const int *src = reinterpret_cast<const int *>(a.model);
-        int *dst = reinterpret_cast<int *>(&s.fw.m);
-        for (int i = threadIdx.x; i < (int)(sizeof(RobotModelDev) / sizeof(int)); i += 256) dst[i] = src[i];
+        stage_model<256>(a.model, &s.fw.m);
     }
     if (threadIdx.x < 64) s.ctl.ready[threadIdx.x] = 0;
     if (threadIdx.x == 0) { s.ctl.state_ready = 0; s.ctl.hand_count = 0; s.ctl.done_tick = 0x7fffffff; s.ctl.stamp = 0; s.args = a;
@@ -2117,7 +2149,8 @@ __global__ __launch_bounds__(1024) void ik_select_kernel(const IkBatchArgs a, in
 }
 
 // ------------------------------------------------------------ small helper kernels ---
-__global__ void ik_centroidal_state_kernel(const RobotModelDev *model, const double *x, double *out9, int B) {
+// (64-thread workgroups with the whole register file: at the default bound hipcc built these two for 128 registers, 570 values in scratch)
+__global__ __launch_bounds__(64) void ik_centroidal_state_kernel(const RobotModelDev *model, const double *x, double *out9, int B) {
     const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     Pass1 p1;
@@ -2130,7 +2163,7 @@ __global__ void ik_centroidal_state_kernel(const RobotModelDev *model, const dou
     }
 }
 
-__global__ void ik_com_mom_kernel(const RobotModelDev *model, const double *xs, double *com, double *mom, int n) {
+__global__ __launch_bounds__(64) void ik_com_mom_kernel(const RobotModelDev *model, const double *xs, double *com, double *mom, int n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Pass1 p1;
@@ -2177,24 +2210,23 @@ __global__ void ik_publish_active_kernel(const int *active, const int *err, cons
 // com / momentum references of the IK tracking tasks from the centroidal solution X
 // (KinoDynMP::optimize, kino_dyn.cpp:50-56: rows 0..T-1 running, row T terminal; mom = [m v, L])
 __global__ void kd_fill_refs_kernel(double *tasks, const double *X, double m, int B, int H, int T) {
+    // one thread per ELEMENT (nine per node: neighbouring lanes write neighbouring words; one thread per node wrote nine words at a
+    // stride of 264 bytes each: 190 us for 45 K nodes)
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= (long)B * (T + 1)) return;
-    const long b = id / (T + 1);
-    const int t = (int)(id % (T + 1));
-    double *tk = tasks + id * kNodeTaskDoubles;
-    const double *Xk = X + b * 9L * (H + 1) + 9L * t;
-    for (int c = 0; c < 3; ++c) {
-        tk[5 * kFrameSlots + 1 + c] = Xk[c];
-        tk[5 * kFrameSlots + 5 + c] = m * Xk[3 + c];
-        tk[5 * kFrameSlots + 8 + c] = Xk[6 + c];
-    }
+    if (id >= 9L * B * (T + 1)) return;
+    const long node = id / 9;
+    const int e = (int)(id % 9), g = e / 3, c = e % 3;      // g: 0 CoM, 1 linear momentum (m v), 2 angular momentum
+    const long b = node / (T + 1);
+    const int t = (int)(node % (T + 1));
+    const double v = X[b * 9L * (H + 1) + 9L * t + e];
+    tasks[node * kNodeTaskDoubles + 5 * kFrameSlots + (g == 0 ? 1 : g == 1 ? 5 : 8) + c] = g == 1 ? m * v : v;
 }
 
 }  // namespace
 
 hipError_t ik_launch_fill_refs(double *tasks, const double *X, double m, int B, int H, int T, hipStream_t st) {
-    const long n = (long)B * (T + 1);
-    hipLaunchKernelGGL(kd_fill_refs_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, tasks, X, m, B, H, T);
+    const long n = 9L * B * (T + 1);
+    hipLaunchKernelGGL(kd_fill_refs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tasks, X, m, B, H, T);
     return hipGetLastError();
 }
 hipError_t ik_launch_state_ops_selftest(const double *x0, const double *x1, const double *dx, int n, double *dq, double *dr, double *iq, double *ir,
