@@ -276,6 +276,7 @@ def summary(out):
     """The numbers a reader of the line's tail needs, flat and last: per KinoDyn leg ms per batch solve, speed-up over the CPU port
     on all host cores and the dominant kernel; the batch-1 latencies."""
     s = {"headline_ms_per_step": out.get("ms_per_step"), "headline_solves_per_s": out.get("value"),
+         "headline_waves_per_simd": out.get("roofline", {}).get("waves_per_simd"),
          "batch_6144_solves_per_s": out.get("batch_6144", {}).get("value") if isinstance(out.get("batch_6144"), dict) else None,
          "headline_speedup_vs_cpu_all_cores": out.get("speedup_vs_cpu_all_cores"),
          "headline_speedup_vs_matrix_free_cpu": out.get("speedup_vs_matrix_free_cpu"), "p50_latency_ms_batch1": out.get("p50_latency_ms_batch1")}

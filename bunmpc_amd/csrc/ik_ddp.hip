@@ -612,7 +612,10 @@ __device__ __noinline__ void calc1_assemble(long b_, int t_, int h_) {
     calc_assemble(a, b, t, g_calc1.nd[wave][h], ws, L, lane, batch_ptr(a.state_w, a.s_state_w, b), batch_ptr(a.ctrl_w, a.s_ctrl_w, b),
                   ws + L.fs + (long)t * kNDX);
 }
-__global__ __launch_bounds__(128, 2) void ik_calcdiff1_kernel(const IkBatchArgs a) {
+#ifndef CALC1_WPE
+#define CALC1_WPE 2
+#endif
+__global__ __launch_bounds__(128, CALC1_WPE) void ik_calcdiff1_kernel(const IkBatchArgs a) {
     Calc1Lds &s = g_calc1;
     const int nn = a.T + 1, groups = (nn + kCalcNodes - 1) / kCalcNodes;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
