@@ -126,6 +126,17 @@ def test_batch_descriptor_validation():
     assert b"64" in _lib.lib().bmpc_last_error()
 
 
+def test_dispatch_knobs_round_trip(hiplib):
+    """The dispatch switches of the batch entry points are plain process-wide settings: each setter returns the value it replaces
+    (no GPU needed), and their defaults are the documented ones (include/bunmpc.h)."""
+    for name, default, other in (("bmpc_set_three_per_wave", 2, 0), ("bmpc_set_two_waves_per_simd", 2, 1), ("bmpc_set_work_stealing", 1, 0),
+                                 ("bmpc_set_steal_grid", 0, 1536), ("bmpc_set_latency_mapping_max_batch", 1024, 0)):
+        f = getattr(hiplib, name)
+        assert f(other) == default, name
+        assert f(default) == other, name
+    assert hiplib.bmpc_biconvex_last_waves_per_simd() in (1, 2)
+
+
 def test_build_lock_serialises_builders(tmp_path):
     """the ranks of a multi-GPU job start together: whoever holds bunmpc_amd.build.build_lock() builds, the others wait"""
     import subprocess
