@@ -155,6 +155,7 @@ _SIGS = {
     "bmpc_id_batch_device": (_I, [_P, _P]),
     "bmpc_perturb_batch_device": (_I, [_P, _P]),
     "bmpc_ik_set_speculative_below": (_I, [_I]),
+    "bmpc_ik_set_spec_one_wave_above": (_I, [_I]),
     "bmpc_model_create": (_P, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "bmpc_model_destroy": (None, [_P]),
     "bmpc_model_total_mass": (_D, [_P]),

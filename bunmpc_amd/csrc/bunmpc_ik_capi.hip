@@ -169,6 +169,7 @@ bunmpc::IkBatchArgs make_args(int B, int T, int maxiter, const bmpc_model *model
 // bmpc_ik_batch_t.sched.  A DDP loop reads them once, when it starts: a setter called meanwhile (another host thread) changes
 // the next loop, never one that is running.
 std::atomic<int> g_spec_line_search_below{1024};
+std::atomic<int> g_spec_one_wave_above{0};      // (experiment) above this many active problems the speculative line search runs on ONE wave per problem; 0 = never
 std::atomic<int> g_all_steps{0};  // at most this many active problems: all ten step lengths at once, three workgroups per problem
                                   // (0 = never, the default: measured on the MI355X it gains < 1 % on the Go2 H = 60 batch at <= 85 -- one workgroup of
                                   // three waves per CU is the forward kernel's residency -- and loses 2 % on Solo12, EXPERIMENTS.md 9)
@@ -310,6 +311,7 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run, const
     auto enqueue_chunk = [&](int slot) -> int {
         const int chunk = active <= sched.spec_below ? kTailChunk : 1;
         a.fwd_spec = active <= sched.all_steps ? 4 : active <= sched.spec_below / 3 ? 3 : active <= sched.spec_below ? 2 : 0;
+        if (a.fwd_spec == 2 && g_spec_one_wave_above.load() > 0 && active > g_spec_one_wave_above.load()) a.fwd_spec = 1;
         a.bwd_waves = active <= sched.gains_wave_below ? 2 : 1;
         a.n_launch = active;        // the host's latest look at the counter: an upper bound of the active list's length
         for (int k = 0; k < chunk && it < a.maxiter; ++k, ++it) {
@@ -548,6 +550,7 @@ double bmpc_ik_set_express_near(double stop) { return g_express_near.exchange(st
 void bmpc_ik_kernel_occupancy(int *out8) { bunmpc::ik_kernel_occupancy(out8); }
 int bmpc_ik_batch_struct_size(void) { return (int)sizeof(bmpc_ik_batch_t); }
 int bmpc_ik_set_speculative_below(int n_active) { return g_spec_line_search_below.exchange(n_active); }
+int bmpc_ik_set_spec_one_wave_above(int n_active) { return g_spec_one_wave_above.exchange(n_active); }
 double bmpc_model_total_mass(const bmpc_model_t *m) { return m ? m->host.total_mass : 0.0; }
 
 // ----------------------------------------------------------- InverseKinematics ----

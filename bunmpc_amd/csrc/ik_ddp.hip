@@ -2283,7 +2283,8 @@ hipError_t ik_launch_forward(const IkBatchArgs &a, hipStream_t st) {
     const unsigned n = (unsigned)launch_problems(a);
     if (a.fwd_spec == 4) hipLaunchKernelGGL(ik_forward_kernel<3>, dim3(3 * n), dim3(192), 0, st, a);
     else if (a.fwd_spec == 3) hipLaunchKernelGGL(ik_forward_kernel<3>, dim3(n + (a.wide ? 2 * kWideMax : 0)), dim3(192), 0, st, a);
-    else if (a.fwd_spec) hipLaunchKernelGGL(ik_forward_kernel<2>, dim3(n + (a.wide ? 2 * kWideMax : 0)), dim3(128), 0, st, a);
+    else if (a.fwd_spec == 2) hipLaunchKernelGGL(ik_forward_kernel<2>, dim3(n + (a.wide ? 2 * kWideMax : 0)), dim3(128), 0, st, a);
+    else if (a.fwd_spec == 1) hipLaunchKernelGGL(ik_forward_kernel<1>, dim3(n), dim3(64), 0, st, a);      // four step lengths of one problem per wave, every role on that wave
     else hipLaunchKernelGGL(ik_forward_kernel<1>, dim3((n + 3) / 4), dim3(64), 0, st, a);
     return hipGetLastError();
 }

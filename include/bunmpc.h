@@ -301,6 +301,10 @@ void bmpc_ik_layout_trace(int n_col, long *offset, int *iters, int *width);
  * lengths at once on three workgroups per problem.  Default 1024 (one wave per SIMD of an MI355X); 0 = never.  Both return
  * the old value. */
 int bmpc_ik_set_speculative_below(int n_active);
+/* (experiment switch) with MORE than n_active problems iterating -- and at most the bound above -- the side-by-side line search runs
+ * every role of a problem on ONE wave instead of two (as many waves as problems: one round over the chip's SIMDs where two waves per
+ * problem need two).  Default 0 = never.  Returns the old value. */
+int bmpc_ik_set_spec_one_wave_above(int n_active);
 int bmpc_ik_set_all_steps(int n_active);
 /* Riccati-pass scheduling (no effect on results): while at most n_active problems are still iterating, each gets a second
  * wave that computes and stores the gains K, k one node behind the recursion.  Default 512; 0 = never.  Returns the old value. */
