@@ -220,6 +220,17 @@ def pmc_traffic(workload_key):
     return e["traffic_bytes"], "replayed from profiles/pmc_traffic.json (builder's rocprofv3 --pmc run, %s); not measured by this process" % e.get("raw_log", "?")
 
 
+def pmc_valu_busy(workload_key, waves_per_simd):
+    """The SIMDs' VALU occupancy of the headline kernel from the builder's SQ counter run (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per wave
+    x waves per SIMD), replayed like the traffic; None when the committed run was of another build."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            e = json.load(f).get(workload_key) or {}
+    except OSError:
+        return None
+    return e.get("simd_valu_busy_frac") if e.get("waves_per_simd") == waves_per_simd else None
+
+
 def ik_algorithmic_bytes(T, E=4):
     """SURVEY.md 8d, the IK part of one KinoDynMP.optimize: in q, v (37) + per-knot foot targets / flags 4 E H_ik,
     out xs 37 (H_ik + 1) + us 18 H_ik doubles"""
@@ -268,7 +279,8 @@ NOTES = {
     "go2": "synthetic Go2 legs run with mu = 10, not the reference's fixed mu = 1, at which the reference algorithm NaNs for a 15 kg robot "
            "(tests/test_biconvex_gpu.py::test_go2_at_the_references_mu_1_diverges_as_the_oracle)",
     "latency_batch1": "BiconvexMP.optimize(x_init, N) on one problem through the drop-in class: H2D of the inputs, one launch, D2H of X / F / P",
-    "traffic": "roofline.traffic is replayed from profiles/pmc_traffic.json (see roofline.traffic_source), never measured by this process",
+    "traffic": "roofline.traffic and roofline.valu.simd_busy_frac_pmc are replayed from profiles/pmc_traffic.json (see roofline.traffic_source; "
+               "the latter: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per wave x waves per SIMD, profiles/r04_pmc_sq.txt), never measured by this process",
 }
 
 
@@ -492,7 +504,8 @@ def biconvex_leg(D, args):
                      "valu": {"model_flops_per_launch": flops,
                               "achieved_tflops": flops / (kern_ms * 1e-3) / 1e12,
                               "peak_tflops": FP64_VALU_PEAK_TF,
-                              "frac": flops / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF}},
+                              "frac": flops / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
+                              "simd_busy_frac_pmc": pmc_valu_busy(wkey, wpe)}},
         "diverged": int(counts[0]), "fista_iters_per_solve": counts[1] / (B * W),
     }
     return out, pb

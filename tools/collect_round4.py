@@ -65,6 +65,19 @@ for w, key in keys.items():
 open("profiles/%s_pmc_hbm.txt" % rnd, "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1)
 shutil.copy("gpurun_out/pmc_%s_sq.txt" % tag, "profiles/%s_pmc_sq.txt" % rnd)
+# the headline kernel's VALU occupancy from that SQ pass: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per wave x the waves a SIMD holds (the
+# grid of 2048 waves over 1024 SIMDs at the build's two waves per SIMD) -- what bench.py replays as roofline.valu.simd_busy_frac_pmc
+sq = {}
+for line in open("profiles/%s_pmc_sq.txt" % rnd):
+    parts = line.split()
+    if len(parts) >= 2 and parts[0].startswith("SQ_"):
+        sq[parts[0]] = float(parts[1])
+if "SQ_ACTIVE_INST_VALU" in sq and "SQ_WAVE_CYCLES" in sq:
+    per_wave = sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"]
+    hk = keys["biconvex"]
+    traffic[hk].update(valu_active_per_wave_cycle=round(per_wave, 4), waves_per_simd=2, simd_valu_busy_frac=round(min(1.0, 2 * per_wave), 4),
+                       valu_insts_per_wave=int(sq.get("SQ_INSTS_VALU", 0) / max(sq.get("SQ_WAVES", 1), 1)), sq_log="%s_pmc_sq.txt" % rnd)
+    json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1)
 print("\n".join(lines))
 # BASELINE config 3's kernels
 cfg3 = []
