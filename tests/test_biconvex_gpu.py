@@ -348,6 +348,54 @@ def test_two_waves_per_simd_build_is_bit_identical(hiplib, mapping, config, B, H
         assert np.array_equal(out[1][k], out[0][k], equal_nan=True), k
 
 
+def test_three_per_wave_at_two_waves_per_simd_full_chip(oracle, hiplib):
+    """B = 6144: the default dispatch runs 2048 waves of three problems, two per SIMD (the instantiation no small batch reaches without
+    forcing it).  Everything bit for bit as from the one-wave-per-SIMD build of the same mapping, and a sample against the CPU oracle."""
+    from bunmpc_amd import batch as bbm
+    B = 6144
+    b = problems.make_batch("solo12_trot", B)
+    out = {}
+    for mode in (2, 0):
+        old = hiplib.bmpc_set_two_waves_per_simd(mode)
+        try:
+            dev = bbm.DeviceBatch(b, num_iters=10, keep_hist=True)
+            dev.solve()
+            out[mode] = dev.results()
+            assert hiplib.bmpc_biconvex_last_lanes_per_problem() == 21 and hiplib.bmpc_biconvex_last_waves_per_simd() == (2 if mode else 1)
+        finally:
+            hiplib.bmpc_set_two_waves_per_simd(old)
+    for k in ("X", "F", "P", "L_x", "L_f", "stats", "trace", "hist", "dyn_viol"):
+        assert np.array_equal(out[2][k], out[0][k], equal_nan=True), k
+    idx = np.arange(0, B, B // 48)[:48]
+    ref = oracle.solve_batch(b.take(idx), num_iters=10)
+    assert np.array_equal(out[2]["stats"][idx], ref["stats"])
+    for k in ("X", "F"):
+        e = np.linalg.norm(out[2][k][idx] - ref[k], axis=1) / np.maximum(np.linalg.norm(ref[k], axis=1), 1e-300)
+        assert e.max() < TOL, (k, e.max())
+
+
+def test_work_stealing_kernel_at_two_waves_per_simd(hiplib):
+    """The work-stealing kernel's two-waves-per-SIMD instantiation (never the default's choice: slower; a forced launch): a grid of 1536
+    waves over 4099 problems at num_iters = 100, results bit for bit the one-wave launch's."""
+    from bunmpc_amd import batch as bbm
+    b = problems.make_batch("solo12_trot", 4099)
+    out = {}
+    for mode in (1, 0):
+        old = hiplib.bmpc_set_two_waves_per_simd(mode)
+        oldg = hiplib.bmpc_set_steal_grid(1536 if mode else 0)
+        try:
+            dev = bbm.DeviceBatch(b, num_iters=100, keep_hist=True)
+            dev.solve()
+            out[mode] = dev.results()
+            assert hiplib.bmpc_biconvex_last_kernel_name().decode() == "biconvex_admm_steal_kernel" and hiplib.bmpc_biconvex_last_waves_per_simd() == mode + 1
+        finally:
+            hiplib.bmpc_set_two_waves_per_simd(old)
+            hiplib.bmpc_set_steal_grid(oldg)
+    for k in ("X", "F", "P", "L_x", "L_f", "stats", "trace"):
+        assert np.array_equal(out[1][k], out[0][k]), k
+    assert np.allclose(out[1]["dyn_viol"], out[0]["dyn_viol"], rtol=1e-12, atol=0)
+
+
 def test_two_waves_per_simd_raw_form_is_bit_identical(hiplib, mapping):
     """... and the raw cost / bound form (set_cost_x / set_bounds_x / set_cost_f given explicitly, with and without a linear force
     cost), whose instantiations are separate kernels."""
