@@ -56,6 +56,11 @@ template <typename R, int LPP, int E, bool RAW, bool HASQF, int WPE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void biconvex_admm_kernel(const BatchArgs a) {
     admm_body<R, LPP, E, RAW, HASQF, false, WPE == 2>(a);
 }
+// horizons of 64 .. 255 knots: one problem per workgroup of WAVES waves (biconvex_admm_body.h: WAVES)
+template <int WAVES, bool RAW, bool HASQF>
+__global__ __launch_bounds__(64 * WAVES) void biconvex_admm_wg_kernel(const BatchArgs a) {
+    admm_body<double, 64, 4, RAW, HASQF, false, false, WAVES>(a);
+}
 // the work-stealing variant (biconvex_admm_body.h: STEAL): three problems per wave, harness form, fp64
 template <int WPE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void biconvex_admm_steal_kernel(const BatchArgs a) {
@@ -90,6 +95,23 @@ hipError_t launch(const BatchArgs &a, bool two_per_simd, hipStream_t stream) {
     if (two_per_simd) hipLaunchKernelGGL((biconvex_admm_kernel<double, LPP, 4, RAW, HASQF, 2>), dim3(grid), dim3(64), lds, stream, a);
     else hipLaunchKernelGGL((biconvex_admm_kernel<double, LPP, 4, RAW, HASQF, 1>), dim3(grid), dim3(64), lds, stream, a);
     return hipGetLastError();
+}
+
+template <int WAVES, bool RAW, bool HASQF>
+hipError_t launch_wg(const BatchArgs &a, hipStream_t stream) {
+    const size_t lds = sizeof(double) * (kLdsZeros + (size_t)kSegLds + (size_t)kKnotLds * (size_t)(a.H + 1) + (size_t)WAVES * 40);
+    static std::once_flag once;      // (more than the 64 KB a kernel may take without asking, from 209 knots on)
+    static hipError_t attr = hipSuccess;
+    std::call_once(once, [] { attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&biconvex_admm_wg_kernel<WAVES, RAW, HASQF>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); });
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((biconvex_admm_wg_kernel<WAVES, RAW, HASQF>), dim3((unsigned)a.B), dim3(64 * WAVES), lds, stream, a);
+    return hipGetLastError();
+}
+template <int WAVES>
+hipError_t launch_wg_form(const BatchArgs &a, hipStream_t stream) {
+    if (a.precision != 0) return hipErrorInvalidValue;      // (fp64 only)
+    if (!a.raw) return launch_wg<WAVES, false, false>(a, stream);
+    return a.qf ? launch_wg<WAVES, true, true>(a, stream) : launch_wg<WAVES, true, false>(a, stream);
 }
 
 // FISTA's momentum coefficients: t+ = 1 + sqrt(1 + 4 t^2)/2 (sic, fista.cpp:34), c_k = (t_k - 1)/t_{k+1} -- a function of k alone, so
@@ -247,6 +269,11 @@ hipError_t launch_biconvex_admm(const BatchArgs &args, int n_eff, hipStream_t st
         const bool w2 = two_per_simd_pays(a, 3);
         t_last_wpe = w2 ? 2 : 1;
         return launch_lpp<21>(a, w2, stream);
+    }
+    if (k > 64) {      // 65 .. 256 knots: a workgroup of two or four waves per problem
+        t_last_kernel = "biconvex_admm_wg_kernel";
+        t_last_lpp = k <= 128 ? 128 : 256;
+        return k <= 128 ? launch_wg_form<2>(a, stream) : launch_wg_form<4>(a, stream);
     }
     t_last_lpp = k <= 32 ? 32 : 64;
     const bool w2 = two_per_simd_pays(a, 64 / t_last_lpp);

@@ -31,16 +31,25 @@
 // sums of its step are being reduced -- for the momentum step, and leaves x_{k+1} there under the mask of the problems still
 // iterating, which is also the latch of a finishing problem.  36 registers less across the loops than two register copies whose
 // roles swap: both loops are free of scratch accesses at 256 registers.  Same operations in the same order: same bits.
-template <typename R, int LPP, int E, bool RAW, bool HASQF, bool STEAL = false, bool XLDS = false>
+//
+// WAVES > 1 (round 4; horizons of 64 .. 255 knots: the reference's own sweep of solve times goes to 10 s horizons,
+// examples/analysis/solve_times_test.py): ONE problem per WORKGROUP of WAVES wave64s, knot t on thread t.  The knot t <-> t +- 1
+// exchanges cross the wave boundaries through LDS (lane 0 / lane 63 of every wave leave their values, one workgroup barrier, the
+// neighbour wave's edge lane picks them up), the segment sums are the waves' sums added in wave order by every wave (same bits
+// everywhere, so every decision stays workgroup-uniform and the barriers sit in uniform control flow); buffers alternate between
+// two copies, so one barrier per exchange is enough.  Everything else is the one-wave code.
+template <typename R, int LPP, int E, bool RAW, bool HASQF, bool STEAL = false, bool XLDS = false, int WAVES = 1>
 __device__ __forceinline__ void admm_body(const BatchArgs &a) {
+    constexpr bool MW = WAVES > 1;
+    static_assert(!MW || (LPP == 64 && !STEAL && !XLDS && sizeof(R) == sizeof(double)), "several waves per problem: fp64, one problem per workgroup");
     extern __shared__ double lds_raw[];
     constexpr int NF = 3 * E;           // force variables per knot
     constexpr int NB = RAW ? 9 : 3;     // bounded components per knot
-    const int lane = threadIdx.x & 63;
-    const int t = lane % LPP;           // knot owned by this lane
-    const int seg = lane / LPP;
+    const int lane = threadIdx.x & 63, wv = MW ? (int)(threadIdx.x >> 6) : 0;
+    const int t = MW ? (int)threadIdx.x : lane % LPP;           // knot owned by this lane
+    const int seg = MW ? 0 : lane / LPP;
     const int H = a.H;
-    long prob = (long)blockIdx.x * (64 / LPP) + seg;      // (STEAL: the segment's FIRST problem)
+    long prob = MW ? (long)blockIdx.x : (long)blockIdx.x * (64 / LPP) + seg;      // (STEAL: the segment's FIRST problem)
     // STEAL: the lane's place in its segment decides what it owns; whether the segment has a problem at all is the `alive` mask's business
     const bool pvalid = seg < 64 / LPP && (STEAL || prob < a.B);      // (LPP = 21: lane 63 belongs to no segment)
     const bool kvalid = pvalid && t <= H;  // owns knot t (X block t)
@@ -69,6 +78,43 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
     R *PIg = Sg, *Xg = Sg + kSegLds, *Pg = Xg + 9, *Fg = Xg + 18, *Rg = Xg + 18 + NF;      // (PIg: lane 0's only)
     const R *Szr = rvalid ? Sg : zeros, *Szk = kvalid ? Sg : zeros;
     const R *Fz = Szr + kSegLds + 18, *RFz = Szr + kSegLds + 18 + NF, *Xz = Szk + kSegLds, *RXz = Szk + kSegLds + 18 + NF;
+    // knot t <-> t +- 1 and the sums over a problem's knots: within the wave by DPP, across a workgroup's waves (MW) through LDS
+    double *const xch = reinterpret_cast<double *>(zeros) + kLdsZeros + kSegLds + (long)(H + 1) * kKnotLds;      // MW: [2][WAVES][9] next, [2][WAVES][9] previous, [2][WAVES][2] sums
+    int par_n = 0, par_p = 0, par_s = 0;
+    auto shift_next = [&](const auto &v, auto &o) {      // o = v of knot t + 1 (0 behind the last lane)
+        constexpr int N = (int)(sizeof(v) / sizeof(v[0]));
+        UNROLL for (int l = 0; l < N; ++l) o[l] = from_next(v[l]);
+        if (MW) {
+            double *buf = xch + par_n * (WAVES * 9);
+            if (lane == 0) { UNROLL for (int l = 0; l < N; ++l) buf[wv * 9 + l] = (double)v[l]; }
+            __syncthreads();
+            if (lane == 63 && wv + 1 < WAVES) { UNROLL for (int l = 0; l < N; ++l) o[l] = (R)buf[(wv + 1) * 9 + l]; }
+            par_n ^= 1;
+        }
+    };
+    auto shift_prev = [&](const auto &v, auto &o) {      // o = v of knot t - 1 (0 in front of the first lane)
+        constexpr int N = (int)(sizeof(v) / sizeof(v[0]));
+        UNROLL for (int l = 0; l < N; ++l) o[l] = from_prev(v[l]);
+        if (MW) {
+            double *buf = xch + 2 * WAVES * 9 + par_p * (WAVES * 9);
+            if (lane == 63) { UNROLL for (int l = 0; l < N; ++l) buf[wv * 9 + l] = (double)v[l]; }
+            __syncthreads();
+            if (lane == 0 && wv > 0) { UNROLL for (int l = 0; l < N; ++l) o[l] = (R)buf[(wv - 1) * 9 + l]; }
+            par_p ^= 1;
+        }
+    };
+    auto sum2 = [&](double &s0, double &s1) {      // both sums over the problem's knots (seg_sum2's contract; MW: in every lane)
+        seg_sum2<LPP>(s0, s1);
+        if (MW) {
+            double *buf = xch + 4 * WAVES * 9 + par_s * (WAVES * 2);
+            if (lane == 0) { buf[2 * wv] = s0; buf[2 * wv + 1] = s1; }
+            __syncthreads();
+            double t0 = buf[0], t1 = buf[1];
+            UNROLL for (int w = 1; w < WAVES; ++w) { t0 += buf[2 * w]; t1 += buf[2 * w + 1]; }
+            s0 = t0; s1 = t1;
+            par_s ^= 1;
+        }
+    };
     // Global arrays are addressed as a WAVE-UNIFORM base (the block of the wave's first problem: scalar registers) plus a 32-bit
     // per-lane byte offset (problem within the wave, knot): `global_load v, v_off, s[base]`.  A 64-bit pointer per lane and array
     // -- what `a.X + pb * nx + 9 * t` makes -- held some thirty vector registers over both FISTA loops, and they were what the
@@ -77,7 +123,7 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
     // are unconditional -- straight-line code in which base + offset folds into the instruction, instead of some sixty
     // exec-masked blocks each needing the address as a 64-bit register pair -- and what a lane has no business with is
     // replaced by zero after the load (ldz).  Stores stay conditional.
-    const long wave0 = STEAL ? 0L : (long)blockIdx.x * (64 / LPP);
+    const long wave0 = STEAL ? 0L : (MW ? (long)blockIdx.x : (long)blockIdx.x * (64 / LPP));
     unsigned sl = STEAL ? (unsigned)(pvalid && prob < a.B ? prob : 0) : (pvalid ? (unsigned)seg : 0u);      // STEAL: the problem index itself
     const unsigned tk = (unsigned)(t <= H ? t : H), tr = (unsigned)(t < H ? t : H - 1);
     struct Off { unsigned X, PI, F, K, P9; };
@@ -101,7 +147,8 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
     const double *const cmtab = a.cmtab;      // (wave-uniform reads: through the scalar cache)
 
     R dt = ldz<R>(a.dt + wave0 * H, oK, 0, rvalid);
-    R dtp = from_prev(dt);  // dt of knot t-1 (0 for t == 0: previous lane is a dead/terminal lane)
+    R dtp;  // dt of knot t-1 (0 for t == 0: previous lane is a dead/terminal lane)
+    { const R d1[1] = {dt}; R o1[1]; shift_prev(d1, o1); dtp = o1[0]; }
     const bool cold = a.cold_start != 0;      // 1: fresh solver object (iterates and step constants reset); 2: iterates only --
     const bool fresh_L = a.cold_start == 1;   // FISTA's L_ is set in the constructor and survives every optimize call (fista.hpp:52)
     const double L0x = a.L0_x, L0f = a.L0_f;      // (locals: read through `a` inside the lambda below, the two arguments got a stack copy)
@@ -228,9 +275,11 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
             R X[9];
             UNROLL for (int l = 0; l < 9; ++l) X[l] = kvalid ? Xg[l] : R(0);
             // bPk rows 9t+3..8 = -b_x + P, b_x = X_{t+1} - X_t (+g dt)   (centroidal.cpp:60-65)
-            R bpk[6];
+            R bpk[6], Xv[6], Xvn[6];
+            UNROLL for (int k = 0; k < 6; ++k) Xv[k] = X[3 + k];
+            shift_next(Xv, Xvn);
             UNROLL for (int k = 0; k < 6; ++k) {
-                const R xn = from_next(X[3 + k]);
+                const R xn = Xvn[k];
                 R bx = xn - X[3 + k];
                 if (k == 2) bx += R(kGravity) * dt;
                 bpk[k] = rvalid ? (-bx + Pg[3 + k]) : R(0);
@@ -353,7 +402,7 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
                         UNROLL for (int k = 0; k < 6; ++k) ro[k] = RFz[k];
                     }
                     double g2s = (double)g2, cvs = (double)cv;
-                    seg_sum2<LPP>(g2s, cvs);
+                    sum2(g2s, cvs);
                     // fista.cpp:14-17: G = sqrt(g2); retry if cv > (L/2) G*G; done if G < tol.  G*G and g2
                     // differ by a few ulp, so outside a 1e-14 relative band the sqrt cannot change either
                     // decision; inside it the reference expression is evaluated as written.
@@ -491,7 +540,7 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
             // u = A_f v + bPk on row-block t; vn = v of knot t+1
             auto applyA = [&](const R (&v)[9], R (&u)[9]) {
                 R vn[9];
-                UNROLL for (int l = 0; l < 9; ++l) vn[l] = from_next(v[l]);
+                shift_next(v, vn);
                 R w[9];
                 UNROLL for (int l = 0; l < 9; ++l) w[l] = v[l] - vn[l];
                 UNROLL for (int k = 0; k < 3; ++k) w[k] += dt * vn[3 + k];
@@ -520,7 +569,7 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
                     {   // half gradient Q y + q/2 + rho A_f^T (A_f y + bPk), step, box projection (fista.cpp:10); inside the retry
                         // loop like the force step's
                         R z[9], wp[9];
-                        UNROLL for (int l = 0; l < 9; ++l) wp[l] = from_prev(ry[l]);  // row-block t-1 (0 for t == 0)
+                        shift_prev(ry, wp);  // row-block t-1 (0 for t == 0)
                         UNROLL for (int l = 0; l < 9; ++l) z[l] = ry[l] - wp[l];
                         UNROLL for (int k = 0; k < 3; ++k) z[3 + k] = fmaR(dtp, wp[k], z[3 + k]);
                         z[0] += SZ * ry[7] - SY * ry[8];
@@ -545,7 +594,7 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
                     cv = fmaR(rho, e2, cv);
                     if (XLDS) { UNROLL for (int l = 0; l < 9; ++l) { xo[l] = Xz[l]; ro[l] = RXz[l]; } }      // (see the force step)
                     double g2s = (double)g2, cvs = (double)cv;
-                    seg_sum2<LPP>(g2s, cvs);
+                    sum2(g2s, cvs);
                     const double Lh = (double)L_x * 0.5, rhs = Lh * g2s;   // see the force loop for the sqrt-free form
                     mask_t bt = __ballot(cvs > rhs);
                     done = __ballot(g2s < tol2);
@@ -600,7 +649,7 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
             double v2 = 0;   // the dynamics violation is accumulated in fp64 whatever R is
             {
                 R xn[9], w[9];
-                UNROLL for (int l = 0; l < 9; ++l) xn[l] = from_next(fin[l]);
+                shift_next(fin, xn);
                 UNROLL for (int l = 0; l < 9; ++l) w[l] = fin[l] - xn[l];
                 UNROLL for (int k = 0; k < 3; ++k) w[k] += dt * xn[3 + k];
                 w[6] += SY * fin[2] - SZ * fin[1];
@@ -618,7 +667,7 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
                 if (al && rvalid) { UNROLL for (int l = 0; l < 9; ++l) Pg[l] += dr[l]; }
                 if (al && l0) { UNROLL for (int l = 0; l < 9; ++l) PIg[l] += dx0[l]; }
             }
-            v2 = seg_sum<LPP>(v2);
+            if (MW) { double z2 = 0.0; sum2(v2, z2); } else v2 = seg_sum<LPP>(v2);
             const double nrm = sqrt(v2);
             if (lanes(alive)) {
                 last_viol = nrm;

@@ -57,7 +57,7 @@ constexpr int kKnotLds = 39;           // LDS elements per knot of a problem (bi
 constexpr int kSegLds = 15;            // ... and per problem in front of its knots (the x_init rows' multipliers, 9; XLDS: step constants, violation, counters)
 constexpr int kLdsZeros = 54;          // zeros in LDS in front of all that (lanes without a knot read them)
 constexpr int kMaxFistaIters = 4096;  // length of the momentum table (one per device, momentum_table below; the one-problem-per-wave kernel keeps its own in LDS: 32 KB + <= 30 KB of iterates < 64 KB)
-constexpr int kMaxKnots = 64;  // H + 1 <= 64: one knot per lane, one problem per <=64 lanes
+constexpr int kMaxKnots = 256; // H + 1 <= 256: one knot per lane, one problem per <= 64 lanes of a wave, or (65 .. 256 knots) per workgroup of 2 / 4 waves
 
 // Launch the batched ADMM kernel on `stream`.  Returns hipSuccess or the launch error;
 // hipErrorInvalidValue for unsupported shapes (n_eff != 4, H + 1 > 64).

@@ -70,7 +70,8 @@ int check_batch(const bmpc_batch_t *d) {
     if (d->B < 0 || d->n_col < 1) return fail(BMPC_BAD_ARG, "B < 0 or n_col < 1");
     if (d->n_eff != 4) return fail(BMPC_BAD_ARG, "only n_eff == 4 is built");
     if (d->n_col + 1 > bunmpc::kMaxKnots)
-        return fail(BMPC_BAD_ARG, "n_col + 1 > 64 knots is not supported by the one-knot-per-lane kernel");
+        return fail(BMPC_BAD_ARG, "n_col + 1 > 256 knots is not supported (one knot per lane, at most four waves per problem)");
+    if (d->n_col + 1 > 64 && d->precision != 0) return fail(BMPC_BAD_ARG, "n_col + 1 > 64 knots: fp64 only");
     if (d->num_iters < 0 || d->maxit < 0) return fail(BMPC_BAD_ARG, "negative iteration cap");
     if (d->maxit > bunmpc::kMaxFistaIters) return fail(BMPC_BAD_ARG, "maxit > 4096 is not supported");
     if (d->cold_start < 0 || d->cold_start > 2) return fail(BMPC_BAD_ARG, "cold_start must be 0, 1 or 2");

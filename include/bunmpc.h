@@ -116,6 +116,8 @@ int bmpc_biconvex_set_robot_mass(bmpc_biconvex_t *h, double m);
  *       the solve's discrete path per ADMM iteration, what the prefix-parity tests compare with the CPU oracle's
  *   A caller built against an older header must zero-initialise the whole struct (bmpc_batch_defaults does) and check
  *   bmpc_batch_struct_size() == sizeof(bmpc_batch_t).
+ *   Shapes: n_eff = 4; n_col + 1 <= 256 knots (up to 64: 4 / 3 / 2 / 1 problems per wave, fp64 or fp32 iterates; 65 .. 256: one
+ *   problem per workgroup of two / four waves, fp64 -- the horizons of the reference's examples/analysis/solve_times_test.py).
  */
 typedef struct {
     int B, n_col, n_eff, raw;

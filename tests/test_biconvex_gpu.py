@@ -189,9 +189,57 @@ def test_horizons_and_ragged_batches(oracle, mapping, H):
         assert np.median(err) < 1e-8 and np.all(err <= bound), (err, bound)
 
 
+@pytest.mark.parametrize("H,B", [(64, 5), (100, 3), (127, 4), (128, 3), (200, 3), (255, 2)])
+def test_long_horizons_one_problem_per_workgroup(oracle, hiplib, H, B):
+    """Horizons of 64 .. 255 knots (the reference's own sweep of solve times goes to 10 s: examples/analysis/solve_times_test.py) run one
+    problem per workgroup of two / four waves, the neighbour exchanges and the segment sums crossing the wave boundaries through
+    LDS.  Against the CPU oracle: the ADMM and FISTA counts and the iterates inside each problem's measured CPU spread (horizons
+    this long are in the chaotic regime from the first ADMM iteration on: tests/util.py), the harness form and the raw form."""
+    b = problems.make_batch("solo12_trot", B, H=H)
+    ref, spread = cpu_spread(b, 1, oracle, with_numpy=False)
+    got = bb.solve_host(b, num_iters=1, keep_hist=True)
+    assert hiplib.bmpc_biconvex_last_kernel_name().decode() == "biconvex_admm_wg_kernel" and hiplib.bmpc_biconvex_last_lanes_per_problem() == (128 if H + 1 <= 128 else 256)
+    err, bound = within_envelope(got, ref, spread)
+    print("H=%d: err %s bound %s spread %s" % (H, err, bound, spread))
+    assert np.all(err <= bound), (err, bound)
+    calm = spread <= 1e-9
+    assert np.array_equal(got["stats"][calm], ref["stats"][calm])
+    assert np.all(got["stats"][:, 0] == 1) and np.all(np.isfinite(got["X"]))
+    # the force step alone (one ADMM iteration ends with the motion step: compare the FISTA counts of both)
+    assert np.all(np.abs(got["stats"][:, 1:3] - ref["stats"][:, 1:3]) <= np.where(calm, 0, 150)[:, None])
+
+
+@pytest.mark.parametrize("H,B,raw", [(64, 3, False), (65, 2, False), (127, 3, False), (128, 2, True), (129, 2, False), (191, 2, False), (192, 2, True), (255, 2, False)])
+def test_long_horizons_before_the_chaos_sets_in(oracle, hiplib, H, B, raw):
+    """The same kernels with FISTA capped at ten iterations per step and two ADMM iterations: too few for the expansive projection to
+    amplify rounding, so EVERY problem must agree with the strict CPU oracle to rounding -- iterates, multipliers, step constants,
+    every count, the violation history -- whichever wave boundary a knot sits at (knots 63 | 64, 127 | 128, 191 | 192) and with
+    partly filled last waves.  Harness form and raw form."""
+    b = problems.make_batch("solo12_trot", B, H=H)
+    kw = dict(num_iters=2, maxit=10)
+    if not raw:
+        ref = oracle.solve_batch(b, **kw)
+        got = bb.solve_host(b, keep_hist=True, **kw)
+    else:
+        pre = oracle.solve_batch(b, num_iters=0)
+        rng = np.random.default_rng(H)
+        rawd = {k: pre[k] for k in ("Qx", "qx", "lbx", "ubx", "Qf")}
+        rawd["qf"] = rng.normal(0.0, 1e-3, pre["Qf"].shape)
+        X0, F0, P0 = b.warm_start()
+        got = bb.solve_host(b, keep_hist=True, raw=rawd, warm=(X0, F0, P0), **kw)
+        rs = [oracle.biconvex_solve(b.cnt_plan[i], b.dt[i], b.m, b.x_init[i], rawd["Qx"][i], rawd["qx"][i], rawd["Qf"][i], rawd["lbx"][i], rawd["ubx"][i],
+                                    X0[i], F0[i], P0[i], rho=b.rho, qf=rawd["qf"][i], **kw) for i in range(B)]
+        ref = {k: np.stack([np.asarray(r[k]) for r in rs]) for k in ("X", "F", "P", "stats", "L_x", "L_f")}
+    assert hiplib.bmpc_biconvex_last_kernel_name().decode() == "biconvex_admm_wg_kernel"
+    assert np.array_equal(got["stats"], ref["stats"])
+    for k in ("X", "F", "P"):
+        assert np.all(rel_l2(got[k], ref[k]) < 1e-10), (k, rel_l2(got[k], ref[k]))
+    assert np.allclose(got["L_x"], ref["L_x"], rtol=1e-14) and np.allclose(got["L_f"], ref["L_f"], rtol=1e-14)
+
+
 def test_unsupported_shapes_are_refused():
     from bunmpc_amd import _lib
-    b = problems.make_batch("solo12_trot", 1, H=64)
+    b = problems.make_batch("solo12_trot", 1, H=256)
     with pytest.raises(_lib.BmpcError) as e:
         bb.solve_host(b, num_iters=1)
     assert e.value.code == _lib.BAD_ARG

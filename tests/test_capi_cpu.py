@@ -121,9 +121,9 @@ def test_batch_descriptor_validation():
     assert (d.rho, d.mu, d.beta, d.tol, d.exit_tol, d.maxit) == (1e5, 1.0, 1.5, 1e-5, 1e-3, 150)
     d.B, d.n_col = 1, 20
     assert _lib.lib().bmpc_biconvex_solve_batch_host(C.byref(d)) == _lib.BAD_ARG      # missing arrays
-    d.n_col = 64
+    d.n_col = 256
     assert _lib.lib().bmpc_biconvex_solve_batch_host(C.byref(d)) == _lib.BAD_ARG
-    assert b"64" in _lib.lib().bmpc_last_error()
+    assert b"256" in _lib.lib().bmpc_last_error()
 
 
 def test_dispatch_knobs_round_trip(hiplib):
