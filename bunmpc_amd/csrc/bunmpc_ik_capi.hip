@@ -176,7 +176,8 @@ std::atomic<int> g_all_steps{0};  // at most this many active problems: all ten 
 std::atomic<int> g_gains_wave_below{512};   // at most this many active problems: the backward pass gives each a second wave for the gains
                                   // (two waves per problem on the MI355X's 1024 SIMDs; no effect on results)
 std::atomic<int> g_blocking_waits{1};       // the DDP loop's host waits sleep on an interrupt (hipEventBlockingSync) instead of spinning
-constexpr int kMaxIkCol = 63;     // T + 1 <= 64 nodes: the backward pass computes the gaps one lane per node
+constexpr int kMaxIkCol = 255;    // (T + 1 <= 64 nodes: also the fused kernel and the express lane, whose per-node flags sit in LDS; longer horizons run the four lock-step kernels only)
+constexpr int kMaxFusedCol = 63;
 
 // thresholds of ONE DDP loop: field of bmpc_ik_batch_t.sched (0 = the process default, < 0 = never, n > 0 = n)
 struct Sched { int spec_below, all_steps, gains_wave_below; int debug_inject = 0; int express_cap = 0; int fused_direct = 0; };
@@ -276,7 +277,7 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run, const
     if (sched.debug_inject == 1 && a.list) HIP_TRY(hipMemsetAsync(a.list, 0x7f, sizeof(int), st));      // tests: an entry far out of range
     // A handful of problems (the single-problem handles of the drop-in classes above all): every one of them gets a CU of its own
     // from the first iteration on -- the whole DDP in ONE launch of the fused kernel, no host look in between.
-    if (a.list && a.B <= sched.fused_direct && a.maxiter > 0) {
+    if (a.list && a.B <= sched.fused_direct && a.maxiter > 0 && a.T <= kMaxFusedCol) {
         a.iter = 0; a.n_launch = a.B;
         HIP_TRY(bunmpc::ik_launch_fused_tail(a, st));
         HIP_TRY(bunmpc::ik_launch_publish_active(a, 0, w.dev[0], st, a.B));
@@ -304,7 +305,7 @@ int run_ddp(const bunmpc::IkBatchArgs &a0, hipStream_t st, int *iters_run, const
     // while the batch goes on without them.  The decision is the device's (the host would learn of it an iteration late); the
     // host enqueues the pair until a look tells it that the lane has taken its problems, or the window has passed.
     constexpr int kExpressFirstIter = 2, kExpressLastIter = 12;
-    const int express_cap = a.list && a.B >= 64 ? sched.express_cap : 0;
+    const int express_cap = a.list && a.B >= 64 && a.T <= kMaxFusedCol ? sched.express_cap : 0;
     bool express_taken = false;
     int express_enqueued = 0;
     int active = a.B, it = 0, it_end[2] = {0, 0};
@@ -556,7 +557,7 @@ double bmpc_model_total_mass(const bmpc_model_t *m) { return m ? m->host.total_m
 // ----------------------------------------------------------- InverseKinematics ----
 bmpc_ik_t *bmpc_ik_create(const bmpc_model_t *model, int n_col) {
     if (!model || n_col < 1) { ik_fail(BMPC_BAD_ARG, "bad InverseKinematics arguments"); return nullptr; }
-    if (n_col > kMaxIkCol) { ik_fail(BMPC_BAD_ARG, "n_col > 63 is not supported (one lane per node in the gap computation)"); return nullptr; }
+    if (n_col > kMaxIkCol) { ik_fail(BMPC_BAD_ARG, "n_col > 255 is not supported"); return nullptr; }
     auto *h = new bmpc_ik;
     h->model = model; h->n_col = n_col;
     h->dt.assign(n_col, 0.0);
@@ -752,7 +753,7 @@ int bmpc_ik_solve_batch_device(const bmpc_ik_batch_t *d, void *hip_stream) {
     using namespace bunmpc;
     if (!d || !d->model) return ik_fail(BMPC_BAD_ARG, "null batch descriptor / model");
     if (d->B < 0 || d->n_col < 1 || d->maxiter < 1) return ik_fail(BMPC_BAD_ARG, "bad sizes");
-    if (d->n_col > kMaxIkCol) return ik_fail(BMPC_BAD_ARG, "n_col > 63 is not supported");
+    if (d->n_col > kMaxIkCol) return ik_fail(BMPC_BAD_ARG, "n_col > 255 is not supported");
     if (!d->x0 || !d->dt || !d->tasks || !d->state_w || !d->x_reg || !d->ctrl_w || !d->ws || !d->active)
         return ik_fail(BMPC_BAD_ARG, "missing array");
     if (d->B == 0) return BMPC_OK;

@@ -153,10 +153,17 @@ __device__ __forceinline__ long slot_problem(const IkBatchArgs &a, long slot) {
 // is not needed before the elimination and should keep flying across the exchanges in between.
 // Sum of one value per node, taken in the order SolverDDP::calcDiff adds the node costs (node 0 first): lane t holds node t's
 // value (T + 1 <= 64), every lane ends up with the sum.  v_readlane hands the values to the additions one by one.
-__device__ __forceinline__ double sum_nodes_in_turn(double mine, int T) {
+template <class F>
+__device__ __forceinline__ double sum_nodes_in_turn(F node_value, int T) {      // node_value(t) for t <= T, whatever for t > T (not added)
+    const int lane = threadIdx.x & 63;
     double c = 0.0;
-    for (int t = 0; t <= T; ++t)
-        c += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), t), __builtin_amdgcn_readlane(__double2loint(mine), t));
+    for (int base = 0; base <= T; base += 64) {      // (64 nodes at a time: their loads go out side by side, one node per lane)
+        const int node = base + lane;
+        const double mine = node <= T ? node_value(node) : 0.0;
+        const int n = T - base < 63 ? T - base : 63;
+        for (int t = 0; t <= n; ++t)
+            c += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), t), __builtin_amdgcn_readlane(__double2loint(mine), t));
+    }
     return c;
 }
 __device__ __forceinline__ void wave_sync() {
@@ -1007,25 +1014,25 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
         if (!FUSED) {
             // (one lane adding T + 1 values it loads one after the other: a global-memory latency per node, ~0.6 us each -- 18 us of
             // a 240 us pass at T = 30.  The loads go out side by side, one node per lane; the additions keep the reference's order.)
-            const double c = sum_nodes_in_turn(lane <= T ? ws[L.fs + (long)lane * kNDX] : 0.0, T);
+            const double c = sum_nodes_in_turn([&](int node) { return ws[L.fs + (long)node * kNDX]; }, T);
             if (lane == 0) sc[S_COST] = c;
             wave_sync();
         }
         if (!feas) {
             double mx = 0.0;
-            if (lane <= T) {
+            for (int node = lane; node <= T; node += 64) {      // (one node per lane, 64 at a time)
                 double d[kNDX];
-                const double *xa = ws + L.xs + (long)lane * kNX;
-                const double *xb = lane == 0 ? a.x0 + b * kNX : ws + L.xnext + (long)(lane - 1) * kNX;
+                const double *xa = ws + L.xs + (long)node * kNX;
+                const double *xb = node == 0 ? a.x0 + b * kNX : ws + L.xnext + (long)(node - 1) * kNX;
                 state_diff_q(xa, xb, d);
-                UNROLL_RBD for (int i = 0; i < kNDX; ++i) { ws[L.fs + (long)lane * kNDX + i] = d[i]; mx = fmax(mx, fabs(d[i])); }
+                UNROLL_RBD for (int i = 0; i < kNDX; ++i) { ws[L.fs + (long)node * kNDX + i] = d[i]; mx = fmax(mx, fabs(d[i])); }
             }
             feas = !__any(!(mx < 1e-16));       // th_gaptol_
             if (lane == 0) sc[S_FEAS] = feas ? 1.0 : 0.0;
         } else if (!wasfeas) {
             for (long i = lane; i < (long)(T + 1) * kNDX; i += 64) ws[L.fs + i] = 0.0;
         } else {
-            if (lane <= T) ws[L.fs + (long)lane * kNDX] = 0.0;   // the parked node costs
+            for (int node = lane; node <= T; node += 64) ws[L.fs + (long)node * kNDX] = 0.0;   // the parked node costs
         }
         wave_sync();
     }
@@ -1346,7 +1353,7 @@ __device__ __forceinline__ void backward_main_wave(const IkBatchArgs &a, long b,
         if (tk.dead) return;
         if (!gave_up && lane == kQuLane) sc[S_D2] = d2;
         if (recalc && !gave_up) {
-            const double c = sum_nodes_in_turn(lane <= T ? ctl->node_cost[lane] : 0.0, T);
+            const double c = sum_nodes_in_turn([&](int node) { return ctl->node_cost[node]; }, T);      // (the fused kernel: T + 1 <= 64)
             if (lane == 0) sc[S_COST] = c;
         }
         for (;;) {

@@ -202,6 +202,32 @@ def test_kinodyn_batch_go2_h60(oracle):
     print("go2 ik iters", got["ik_iters"], "rel X", rel_l2(got["X"], ref["X"]))
 
 
+@pytest.mark.parametrize("periods,ratio", [(10.0, 1.0), (16.0, 0.5)])
+def test_kinodyn_batch_long_horizons(model, oracle, periods, ratio):
+    """The shapes of the reference's solve-time sweep (examples/analysis/solve_times_test.py: gait horizons of 1 .. 20 periods, ik_hor_ratio
+    = 1): a trot of 10 periods with the IK over the whole horizon (H = H_ik = 100) and of 16 periods (H = 160, H_ik = 80) -- the
+    centroidal solve one problem per workgroup, the IK-DDP on the lock-step kernels.  Centroidal part within the long-horizon envelope
+    of the CPU restatements, the IK-DDP exactly on the references the GPU's own centroidal solution produced."""
+    import dataclasses
+    from bunmpc_amd.kinodyn_batch import KinoDynDeviceBatch
+    gait = dataclasses.replace(problems.TROT, gait_horizon=periods)
+    B = 2
+    wb = problems.make_wb_batch(model, B, gait=gait, ik_hor_ratio=ratio)
+    assert wb.dyn.H == int(periods * 10) and wb.ik_T == int(periods * 10 * ratio)
+    kb = KinoDynDeviceBatch(wb, model, num_iters=10)
+    kb.solve()
+    got = kb.results()
+    ref = oracle.solve_batch(wb.dyn, num_iters=10)
+    assert np.all(rel_l2(got["X"], ref["X"]) < 2e-2) and np.all(np.isfinite(got["X"]))
+    assert np.all(got["ik_status"] == 0)
+    for i in range(B):
+        r = _oracle_ddp(model, wb, i, got["X"][i].reshape(-1, 9))
+        assert r["converged"] and got["ik_iters"][i] == r["iters"], (i, got["ik_iters"][i], r["iters"])
+        assert abs(got["ik_cost"][i] - r["cost"]) <= 1e-7 * abs(r["cost"])
+        assert rel_l2(got["xs"][i].reshape(-1), np.array(r["xs"]).reshape(-1)) < 1e-6
+    print("H %d H_ik %d: ik iters %s rel X %s" % (wb.dyn.H, wb.ik_T, got["ik_iters"], rel_l2(got["X"], ref["X"])))
+
+
 def test_line_search_scheduling_does_not_change_results(model):
     """How the batched DDP is scheduled must not show in its results: step lengths one after the other (four problems per
     wave), four at a time (one problem per workgroup) or all ten at once (three workgroups per problem, the last to arrive
@@ -328,12 +354,13 @@ def test_riccati_pass_that_fails_and_restarts(model):
         assert (g[:, 1] > 1e-2).any()        # within the compared prefix the regularisation has already gone up
 
 
-def test_ik_longest_horizon(model):
-    """n_col = 63 (the largest the kernels take: T + 1 = 64 nodes): regularisation + one foot target per node, the
-    numpy DDP on the same problem as the reference"""
+@pytest.mark.parametrize("T", [63, 64, 130, 200])
+def test_ik_long_horizons(model, T):
+    """n_col = 63 (T + 1 = 64 nodes: the last horizon the fused single-launch kernel takes), 64, 130 and 200 (the horizons of the
+    reference's solve_times_test.py with ik_hor_ratio = 1: the lock-step kernels, node costs and gaps 64 nodes at a time):
+    regularisation + one foot target every fourth node, the numpy DDP on the same problem as the reference"""
     from bunmpc_amd.inverse_kinematics_cpp import InverseKinematics
     from oracle import ik_ddp_np
-    T = 63
     x0 = np.concatenate([Q0, np.zeros(18)])
     target = np.array([0.21, 0.15, 0.03])
 
@@ -356,7 +383,7 @@ def test_ik_longest_horizon(model):
     assert abs(st["cost"] - ref["cost"]) <= 1e-9 * abs(ref["cost"])
     assert rel_l2(np.array(ik.get_xs()).reshape(-1), np.array(ref["xs"]).reshape(-1)) < 1e-8
     with pytest.raises(Exception):
-        InverseKinematics(model, 64)
+        InverseKinematics(model, 256)
 
 
 IK_GOLDEN = sorted(__import__("glob").glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ik_*.npz")))
