@@ -57,9 +57,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     admm_body<R, LPP, E, RAW, HASQF, false, WPE == 2>(a);
 }
 // horizons of 64 .. 255 knots: one problem per workgroup of WAVES waves (biconvex_admm_body.h: WAVES)
-template <int WAVES, bool RAW, bool HASQF>
-__global__ __launch_bounds__(64 * WAVES) void biconvex_admm_wg_kernel(const BatchArgs a) {
-    admm_body<double, 64, 4, RAW, HASQF, false, false, WAVES>(a);
+template <int WAVES, bool RAW, bool HASQF, int WPE>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void biconvex_admm_wg_kernel(const BatchArgs a) {
+    admm_body<double, 64, 4, RAW, HASQF, false, WPE == 2, WAVES>(a);
 }
 // the work-stealing variant (biconvex_admm_body.h: STEAL): three problems per wave, harness form, fp64
 template <int WPE>
@@ -97,21 +97,21 @@ hipError_t launch(const BatchArgs &a, bool two_per_simd, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <int WAVES, bool RAW, bool HASQF>
+template <int WAVES, bool RAW, bool HASQF, int WPE>
 hipError_t launch_wg(const BatchArgs &a, hipStream_t stream) {
     const size_t lds = sizeof(double) * (kLdsZeros + (size_t)kSegLds + (size_t)kKnotLds * (size_t)(a.H + 1) + (size_t)WAVES * 40);
     static std::once_flag once;      // (more than the 64 KB a kernel may take without asking, from 209 knots on)
     static hipError_t attr = hipSuccess;
-    std::call_once(once, [] { attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&biconvex_admm_wg_kernel<WAVES, RAW, HASQF>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); });
+    std::call_once(once, [] { attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&biconvex_admm_wg_kernel<WAVES, RAW, HASQF, WPE>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); });
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((biconvex_admm_wg_kernel<WAVES, RAW, HASQF>), dim3((unsigned)a.B), dim3(64 * WAVES), lds, stream, a);
+    hipLaunchKernelGGL((biconvex_admm_wg_kernel<WAVES, RAW, HASQF, WPE>), dim3((unsigned)a.B), dim3(64 * WAVES), lds, stream, a);
     return hipGetLastError();
 }
-template <int WAVES>
+template <int WAVES, int WPE>
 hipError_t launch_wg_form(const BatchArgs &a, hipStream_t stream) {
     if (a.precision != 0) return hipErrorInvalidValue;      // (fp64 only)
-    if (!a.raw) return launch_wg<WAVES, false, false>(a, stream);
-    return a.qf ? launch_wg<WAVES, true, true>(a, stream) : launch_wg<WAVES, true, false>(a, stream);
+    if (!a.raw) return launch_wg<WAVES, false, false, WPE>(a, stream);
+    return a.qf ? launch_wg<WAVES, true, true, WPE>(a, stream) : launch_wg<WAVES, true, false, WPE>(a, stream);
 }
 
 // FISTA's momentum coefficients: t+ = 1 + sqrt(1 + 4 t^2)/2 (sic, fista.cpp:34), c_k = (t_k - 1)/t_{k+1} -- a function of k alone, so
@@ -273,7 +273,15 @@ hipError_t launch_biconvex_admm(const BatchArgs &args, int n_eff, hipStream_t st
     if (k > 64) {      // 65 .. 256 knots: a workgroup of two or four waves per problem
         t_last_kernel = "biconvex_admm_wg_kernel";
         t_last_lpp = k <= 128 ? 128 : 256;
-        return k <= 128 ? launch_wg_form<2>(a, stream) : launch_wg_form<4>(a, stream);
+        // the two-waves-per-SIMD build when there are more waves than SIMDs -- and, for two waves per problem, when four such workgroups'
+        // LDS fits a CU (at 127 knots only three do: 9.2 ms against 6.9 at B = 1024); four waves per problem: always (11.4-12.6 ms
+        // against 15.9-16.8: tools/horizon_sweep.py)
+        const size_t lds_bytes = sizeof(double) * (kLdsZeros + (size_t)kSegLds + (size_t)kKnotLds * (size_t)k + (size_t)(t_last_lpp / 64) * 40);
+        const bool fits = k > 128 || 4 * lds_bytes <= 160 * 1024;
+        const bool w2 = g_two_per_simd == 1 || (g_two_per_simd == 2 && fits && (long)a.B * (t_last_lpp / 64) > chip_simds());
+        t_last_wpe = w2 ? 2 : 1;
+        if (k <= 128) return w2 ? launch_wg_form<2, 2>(a, stream) : launch_wg_form<2, 1>(a, stream);
+        return w2 ? launch_wg_form<4, 2>(a, stream) : launch_wg_form<4, 1>(a, stream);
     }
     t_last_lpp = k <= 32 ? 32 : 64;
     const bool w2 = two_per_simd_pays(a, 64 / t_last_lpp);

@@ -41,7 +41,8 @@
 template <typename R, int LPP, int E, bool RAW, bool HASQF, bool STEAL = false, bool XLDS = false, int WAVES = 1>
 __device__ __forceinline__ void admm_body(const BatchArgs &a) {
     constexpr bool MW = WAVES > 1;
-    static_assert(!MW || (LPP == 64 && !STEAL && !XLDS && sizeof(R) == sizeof(double)), "several waves per problem: fp64, one problem per workgroup");
+    static_assert(!MW || (LPP == 64 && !STEAL && sizeof(R) == sizeof(double)), "several waves per problem: fp64, one problem per workgroup");
+    constexpr bool PARK = XLDS && !MW;      // (the LDS header is written by lane 0 and read by the whole problem: across waves that would take barriers)
     extern __shared__ double lds_raw[];
     constexpr int NF = 3 * E;           // force variables per knot
     constexpr int NB = RAW ? 9 : 3;     // bounded components per knot
@@ -260,7 +261,7 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
 
         // =================================================================== F step
         {
-            if (XLDS) park_x();
+            if (PARK) park_x();
             const unsigned ph = opaque_zero();      // see opaque_zero (biconvex_lanes.h): the inputs are re-read in each phase
             // XLDS: ... and their offsets re-made from the problem's index (hoisted out of the ADMM loop they were a dozen registers
             // that the 256-register build kept in scratch memory)
@@ -451,7 +452,7 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
 
         // =================================================================== X step
         {
-            if (XLDS) park_f();
+            if (PARK) park_f();
             const unsigned ph = opaque_zero();
             const unsigned sl_ = XLDS ? opaque_copy(sl) : sl;
             const Off o = XLDS ? make_off(sl_) : Off{oX, oPI, oF, oK, oP9};
@@ -556,7 +557,7 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
             UNROLL for (int l = 0; l < 9; ++l) ra[l] = ry[l];
             if (XLDS && kvalid) { UNROLL for (int l = 0; l < 9; ++l) Rg[l] = ry[l]; }
             const double tol2 = tol * tol;
-            if (XLDS) load_xloop();
+            if (PARK) load_xloop();
             R invL = R(2) * (R(1) / L_x);
             mask_t act = alive;
             auto iterate = [&](const R (&xo_reg)[9], const R (&ro_reg)[9], R (&xn)[9], R (&rn)[9], int i) {
@@ -633,7 +634,7 @@ __device__ __forceinline__ void admm_body(const BatchArgs &a) {
             }
             R fin[9];
             UNROLL for (int l = 0; l < 9; ++l) fin[l] = kvalid ? Xg[l] : R(0);
-            if (XLDS) load_rest();
+            if (PARK) load_rest();
             if (XLDS) {     // b_f made again from the contact plan and the forces (same expressions, same bits) instead of six registers held
                             // across the FISTA loop -- which the 256-register build held in scratch memory
                 const unsigned ph2 = opaque_zero();

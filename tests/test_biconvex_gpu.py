@@ -367,12 +367,13 @@ def test_three_problems_per_wave_equal_two_per_wave(oracle, hiplib, mapping, con
 
 
 @pytest.mark.parametrize("config,B,H,iters,warm", [("solo12_trot", 100, None, 10, False), ("solo12_mixed", 31, None, 10, False), ("solo12_trot", 9, 12, 4, False),
-                                                   ("solo12_trot", 5, 28, 3, False), ("go2_bound", 6, 40, 3, False), ("solo12_trot", 33, None, 3, True)])
+                                                   ("solo12_trot", 5, 28, 3, False), ("go2_bound", 6, 40, 3, False), ("solo12_trot", 33, None, 3, True),
+                                                   ("solo12_trot", 3, 100, 2, False), ("solo12_trot", 2, 200, 1, True)])
 def test_two_waves_per_simd_build_is_bit_identical(hiplib, mapping, config, B, H, iters, warm):
     """The fp64 batch kernel has a second build for two waves per SIMD (256 registers: x_k of the FISTA loops and its affine image
     rest in LDS between the iterations, bmpc_set_two_waves_per_simd).  Same operations in the same order: EVERY output bit for bit
     as from the one-wave build -- iterates, step constants, violation history, every per-iteration count -- with 16 / 32 / 64
-    lanes per problem, partly filled waves, the chaotic mixed-gait batch, warm starts with carried step constants."""
+    lanes per problem, two / four waves per problem (horizons of 100 and 200 knots), partly filled waves, the chaotic mixed-gait batch, warm starts with carried step constants."""
     mapping("batch")
     b = problems.make_batch(config, B, H=H) if H else problems.make_batch(config, B)
     old3 = hiplib.bmpc_set_three_per_wave(0)
