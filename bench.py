@@ -278,6 +278,9 @@ NOTES = {
               "prefix parity + per-problem CPU ensembles (tests/util.py, tests/test_parity_envelope_gpu.py, tests/test_ik_gpu.py)",
     "go2": "synthetic Go2 legs run with mu = 10, not the reference's fixed mu = 1, at which the reference algorithm NaNs for a 15 kg robot "
            "(tests/test_biconvex_gpu.py::test_go2_at_the_references_mu_1_diverges_as_the_oracle)",
+    "horizon_200": "informational leg at the far end of the reference's solve-time sweep (10 s horizons); `diverged` there is the reference ALGORITHM's: from "
+                   "~100 knots on its squared-norm cone projection lets a third of these perturbed trot problems overflow to NaN within ten ADMM "
+                   "iterations, in the CPU restatements as on the GPU (tools/scratch/h200_div.py; DESIGN.md 4)",
     "latency_batch1": "BiconvexMP.optimize(x_init, N) on one problem through the drop-in class: H2D of the inputs, one launch, D2H of X / F / P",
     "traffic": "roofline.traffic and roofline.valu.simd_busy_frac_pmc are replayed from profiles/pmc_traffic.json (see roofline.traffic_source; "
                "the latter: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per wave x waves per SIMD, profiles/r04_pmc_sq.txt), never measured by this process",
@@ -290,6 +293,7 @@ def summary(out):
     s = {"headline_ms_per_step": out.get("ms_per_step"), "headline_solves_per_s": out.get("value"),
          "headline_waves_per_simd": out.get("roofline", {}).get("waves_per_simd"),
          "batch_6144_solves_per_s": out.get("batch_6144", {}).get("value") if isinstance(out.get("batch_6144"), dict) else None,
+         "horizon_200_solves_per_s": out.get("horizon_200", {}).get("value") if isinstance(out.get("horizon_200"), dict) else None,
          "headline_speedup_vs_cpu_all_cores": out.get("speedup_vs_cpu_all_cores"),
          "headline_speedup_vs_matrix_free_cpu": out.get("speedup_vs_matrix_free_cpu"), "p50_latency_ms_batch1": out.get("p50_latency_ms_batch1")}
     for key, short in (("kinodyn_full_solve", "kinodyn_solo12"), ("kinodyn_go2_h60", "kinodyn_go2_h60"), ("kinodyn_n100", "kinodyn_n100")):
@@ -526,6 +530,20 @@ def other_batch_size_leg(D, args, B):
             "waves_per_simd": int(bb._lib.lib().bmpc_biconvex_last_waves_per_simd())}
 
 
+def long_horizon_leg(D, args, H=200, B=1024):
+    """Informational: a horizon of the reference's solve-time sweep (examples/analysis/solve_times_test.py goes to 10 s = 200 knots): one
+    problem per workgroup of four waves"""
+    from bunmpc_amd import batch as bb
+    from bunmpc_amd import problems
+    pb = problems.make_batch(args.config, B, H=H, first=D.rank * B)
+    db = bb.DeviceBatch(pb, device=D.dev, num_iters=args.admm_iters, maxit=args.maxit)
+    dt = D.timed(db.solve, 5, 2) / 5
+    r = db.results()
+    return {"H": H, "batch": B, "value": D.world * B / dt, "unit": "solves/s", "ms_per_step": dt * 1e3, "diverged": int((r["stats"][:, 5] != 0).sum()),
+            "kernel": bb._lib.lib().bmpc_biconvex_last_kernel_name().decode(), "lanes_per_problem": int(bb._lib.lib().bmpc_biconvex_last_lanes_per_problem()),
+            "waves_per_simd": int(bb._lib.lib().bmpc_biconvex_last_waves_per_simd())}
+
+
 def fp32_parity_note(pb, args):
     """config 3's residual check in the line: the fp32 kernel against the CPU oracle on a sample of the batch"""
     from bunmpc_amd import batch as bb
@@ -703,6 +721,7 @@ def main():
             return 3 * pb.B / (time.perf_counter() - th)
         if args.config == "solo12_trot" and args.precision == "f64":
             out["batch_6144"] = guarded(lambda: other_batch_size_leg(D, args, 6144))
+            out["horizon_200"] = guarded(lambda: long_horizon_leg(D, args))
         if world == 1 and not args.no_latency:
             lat = guarded(lambda: p50_latency(args.config, args.admm_iters))
             out["p50_latency_ms_batch1"] = lat.get("p50_ms", lat)
