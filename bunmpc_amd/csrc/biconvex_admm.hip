@@ -270,9 +270,9 @@ hipError_t launch_biconvex_admm(const BatchArgs &args, int n_eff, hipStream_t st
         t_last_wpe = w2 ? 2 : 1;
         return launch_lpp<21>(a, w2, stream);
     }
-    if (k > 64) {      // 65 .. 256 knots: a workgroup of two or four waves per problem
+    if (k > 64) {      // 65 .. 256 knots: a workgroup of two, three or four waves per problem
         t_last_kernel = "biconvex_admm_wg_kernel";
-        t_last_lpp = k <= 128 ? 128 : 256;
+        t_last_lpp = k <= 128 ? 128 : (k <= 192 ? 192 : 256);
         // the two-waves-per-SIMD build when there are more waves than SIMDs -- and, for two waves per problem, when four such workgroups'
         // LDS fits a CU (at 127 knots only three do: 9.2 ms against 6.9 at B = 1024); four waves per problem: always (11.4-12.6 ms
         // against 15.9-16.8: tools/horizon_sweep.py)
@@ -281,6 +281,7 @@ hipError_t launch_biconvex_admm(const BatchArgs &args, int n_eff, hipStream_t st
         const bool w2 = g_two_per_simd == 1 || (g_two_per_simd == 2 && fits && (long)a.B * (t_last_lpp / 64) > chip_simds());
         t_last_wpe = w2 ? 2 : 1;
         if (k <= 128) return w2 ? launch_wg_form<2, 2>(a, stream) : launch_wg_form<2, 1>(a, stream);
+        if (k <= 192) return w2 ? launch_wg_form<3, 2>(a, stream) : launch_wg_form<3, 1>(a, stream);
         return w2 ? launch_wg_form<4, 2>(a, stream) : launch_wg_form<4, 1>(a, stream);
     }
     t_last_lpp = k <= 32 ? 32 : 64;

@@ -117,7 +117,7 @@ int bmpc_biconvex_set_robot_mass(bmpc_biconvex_t *h, double m);
  *   A caller built against an older header must zero-initialise the whole struct (bmpc_batch_defaults does) and check
  *   bmpc_batch_struct_size() == sizeof(bmpc_batch_t).
  *   Shapes: n_eff = 4; n_col + 1 <= 256 knots (up to 64: 4 / 3 / 2 / 1 problems per wave, fp64 or fp32 iterates; 65 .. 256: one
- *   problem per workgroup of two / four waves, fp64 -- the horizons of the reference's examples/analysis/solve_times_test.py).
+ *   problem per workgroup of two .. four waves, fp64 -- the horizons of the reference's examples/analysis/solve_times_test.py).
  */
 typedef struct {
     int B, n_col, n_eff, raw;
@@ -177,7 +177,7 @@ int bmpc_set_steal_grid(int waves);
  * other's latencies.  mode 0: never the second, 1: always, 2 (default): when the batch needs more waves than the chip has SIMDs
  * (B = 4096 at n_col = 20 on an MI355X: 2048 waves over 1024 SIMDs).  Returns the old value. */
 int bmpc_set_two_waves_per_simd(int mode);
-/* lanes per problem of the calling host thread's latest batch solve: 16 / 21 / 32 / 64, 0 = the one-problem-per-wave kernel */
+/* lanes per problem of the calling host thread's latest batch solve: 16 / 21 / 32 / 64 (128 / 192 / 256: a workgroup of 2 / 3 / 4 waves), 0 = the one-problem-per-wave kernel */
 int bmpc_biconvex_last_lanes_per_problem(void);
 /* ... and the waves per SIMD its kernel was built for (1 or 2) */
 int bmpc_biconvex_last_waves_per_simd(void);

@@ -198,7 +198,7 @@ def test_long_horizons_one_problem_per_workgroup(oracle, hiplib, H, B):
     b = problems.make_batch("solo12_trot", B, H=H)
     ref, spread = cpu_spread(b, 1, oracle, with_numpy=False)
     got = bb.solve_host(b, num_iters=1, keep_hist=True)
-    assert hiplib.bmpc_biconvex_last_kernel_name().decode() == "biconvex_admm_wg_kernel" and hiplib.bmpc_biconvex_last_lanes_per_problem() == (128 if H + 1 <= 128 else 256)
+    assert hiplib.bmpc_biconvex_last_kernel_name().decode() == "biconvex_admm_wg_kernel" and hiplib.bmpc_biconvex_last_lanes_per_problem() == (128 if H + 1 <= 128 else 192 if H + 1 <= 192 else 256)
     err, bound = within_envelope(got, ref, spread)
     print("H=%d: err %s bound %s spread %s" % (H, err, bound, spread))
     assert np.all(err <= bound), (err, bound)
